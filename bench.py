@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Benchmark of the MCL update (BASELINE.json: particle-beam evaluations per second).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one whole update of the particle set: restore the synthetic cloud
+(device-to-device), velocity-motion sampling with device-generated noise, sector
+range query + beam likelihood, weight normalisation (numpy summation order) and
+order-exact low-variance resampling + gather.  Workload at N=1: configs[1] of
+BASELINE.json -- 2^20 particles x 180 beams on a synthetic 4096^2 occupancy
+grid, float32 particle state.  With N > 1 every rank holds 2^20 particles of one
+N * 2^20 filter (weak scaling).
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_EVAL = 97.2   # 96.96 one-byte grid cells per +-5 deg sector of radius z_max/res + 0.22 B particle state
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--particles", type=int, default=1 << 20, help="particles per GPU")
+    ap.add_argument("--beams", type=int, default=180)
+    ap.add_argument("--map", type=int, default=4096, help="side of the synthetic occupancy grid in cells")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--regime", default="global", choices=["global", "tracking"],
+                    help="global: every step starts from the uniform synthetic cloud; tracking: the filter runs on")
+    ap.add_argument("--cpu-particles", type=int, default=1024, help="particles of the CPU-baseline sample (0 = skip)")
+    return ap.parse_args()
+
+
+def cpu_baseline(grid, angles, X, z_meas, ut, n_particles):
+    """The oracle (numpy restatement of the reference, one core) on a bounded sample of the
+    same workload: one whole update of `n_particles` particles against the full obstacle list."""
+    from oracle import mcl_oracle as O
+    rng = np.random.RandomState(7)
+    Xs = X[:n_particles].copy()
+    noise = rng.randint(-1000, 1001, size=(n_particles, 3, 12)).astype(np.int16)
+    orc = O.OracleMCL(grid, angles, Xs[0].copy())
+    orc.X = Xs
+    t0 = time.perf_counter()
+    orc.z_meas = z_meas
+    orc.X, orc.pm = O.motion(orc.X, ut, 0.1, grid, noise)
+    orc.R, _ = O.sector_query_batch(orc.X, orc.lut, orc.cell, angles)
+    orc.w, orc.logw, _ = O.weights_from_ranges(orc.R, z_meas, orc.pm, orc.sp)
+    lw = orc.logw - np.max(orc.logw)
+    orc.w = np.exp(lw)
+    orc.resample(rng.rand() / n_particles, clamp=True)
+    dt = time.perf_counter() - t0
+    return {"value": n_particles * len(angles) / dt, "unit": "particle-beam evals/s", "cores": 1, "kind": "port",
+            "sample": "%d particles x %d beams, full obstacle list (%d cells), one update in %.1f s; "
+                      "cost is linear in the particle count" % (n_particles, len(angles), len(orc.lut), dt)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from slam_amd import _lib, workload as W
+    from slam_amd.sharded import ShardedFilter
+
+    M, B = a.particles, a.beams
+    grid = W.synthetic_map(a.map)
+    angles = W.beam_angles(B)
+    ctx = _lib.Context(local_rank, _lib.F32 if a.dtype == "f32" else _lib.F64)
+    ctx.set_map(grid, W.RES, W.RES)
+    w4 = np.array([0.97, 0.005, 0.020, 0.005])
+    w4 = w4 / w4.sum()
+    ctx.set_sensor(angles, W.Z_MAX, 0.15, 1.0, w4, 5 * np.pi / 180.0)
+    X_all = W.uniform_particles(grid, M * world)           # identical on every rank
+    X = X_all[rank * M:(rank + 1) * M]
+    ctx.set_particles(X)
+    ctx.snapshot_particles()
+
+    # the true pose follows the controls; its measured ranges are an input of every step
+    n_total = a.warmup + a.steps
+    ctrl = W.controls(n_total)
+    from slam_amd.mc_localization import advance_true_pose
+    x_gt = X_all[0].copy()
+    z_meas = []
+    for (v, om) in ctrl:
+        x_gt = advance_true_pose(x_gt, (v, om), 0.1)
+        z_meas.append(ctx.raycast(x_gt, want_hits=False)[0][0])
+    rs = np.random.RandomState(W.SEED_STREAM)
+    r_draw = rs.rand(n_total) / (M * world)
+    alpha = [4, 2, 4, 4, 4, 2]
+    filt = ShardedFilter(ctx, dist, rank, world, M)
+
+    def one_step(t):
+        if a.regime == "global":
+            ctx.restore_particles_async()
+        v, om = ctrl[t]
+        filt.step(v, om, 0.1, alpha, z_meas[t], r_draw[t], seed=W.SEED_STREAM * 1000 + t)
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for t in range(a.warmup):
+        one_step(t)
+    fence()
+    ctx.timing_enable(True)
+    t0 = time.perf_counter()
+    for t in range(a.warmup, n_total):
+        one_step(t)
+    ctx.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    n_ray, ms_ray = ctx.timing_get(0)
+    n_mot, ms_mot = ctx.timing_get(1)
+    n_res, ms_res = ctx.timing_get(2)
+    ctx.timing_enable(False)
+
+    if rank == 0:
+        evals_step = float(M) * world * B
+        ms_step = elapsed / a.steps * 1e3
+        ray_ms = ms_ray / max(n_ray, 1)
+        achieved = ALGO_BYTES_PER_EVAL * float(M) * B / (ray_ms * 1e-3) / 1e9 if n_ray else None
+        out = {
+            "metric": "particle-beam evals/sec (node) + ms per MCL step, 1M particles x 180 beams",
+            "value": evals_step / (elapsed / a.steps),
+            "unit": "particle-beam evals/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64 geometry predicates + %s state/likelihood" % a.dtype,
+            "data": "synthetic",
+            "config": {"workload": "MCL %d particles/GPU x %d beams on synthetic %dx%d occupancy grid (%.1f%% occupied), "
+                                   "%s state, device noise, log-weights, regime=%s"
+                                   % (M, B, a.map, a.map, 100.0 * float(np.mean(grid == 0)), a.dtype, a.regime),
+                       "particles_per_gpu": M, "beams": B, "map": a.map, "regime": a.regime,
+                       "sharding": "contiguous particle ranges, map replicated" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "kernel": "raycast_kernel (sector query + beam likelihood)",
+                         "kernel_ms": ray_ms, "launches": n_ray,
+                         "algorithmic_bytes_per_eval": ALGO_BYTES_PER_EVAL},
+            "kernel_ms": {"raycast": ray_ms, "motion": ms_mot / max(n_mot, 1),
+                          "normalise+resample+gather": ms_res / max(n_res, 1)},
+        }
+        if world == 1 and a.cpu_particles > 0:
+            out["cpu_baseline"] = cpu_baseline(grid, angles, X, z_meas[0], ctrl[0], a.cpu_particles)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,165 @@
+/*
+ * mclhip.h -- C ABI of libmclhip.so: the Monte Carlo localization update
+ * (motion sampling, sector range query, beam likelihood, weight normalisation,
+ * low-variance resampling) as hand-written HIP kernels for gfx950 (MI355X).
+ *
+ * The reference (trip2eee/slam) is pure Python and has no FFI of its own; the
+ * interface each entry point stands in for is the Python method or expression
+ * cited beside it (paths relative to the reference checkout,
+ * 08_grid_and_montecarlo_localization/ unless another directory is named).
+ *
+ * Conventions
+ *   - plain C, no C++ types, no exceptions across the boundary;
+ *   - every call returns 0 on success and a negative MCLHIP_E_* code on error;
+ *     the message is available from mclhip_last_error();
+ *   - host buffers are borrowed for the duration of the call, contiguous, C order;
+ *   - the library owns all device memory; one context drives one GPU (one
+ *     process per GPU; ranks are combined by the host, see the shard_* calls);
+ *   - a context is not thread-safe: one caller thread per context;
+ *   - calls are synchronous (they return after the device work has finished)
+ *     except mclhip_step_async().
+ */
+#ifndef MCLHIP_H
+#define MCLHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mclhip_ctx mclhip_ctx;
+
+enum {
+  MCLHIP_OK = 0,
+  MCLHIP_E_ARG = -1,     /* bad argument / call order */
+  MCLHIP_E_HIP = -2,     /* a HIP runtime call failed */
+  MCLHIP_E_STATE = -3,   /* map / sensor / particles not set yet */
+  MCLHIP_E_LIMIT = -4    /* size beyond what the kernels support */
+};
+
+/* dtype of the particle state kept on the device */
+enum { MCLHIP_F32 = 0, MCLHIP_F64 = 1 };
+
+/* how mclhip_normalise forms the weights it normalises */
+enum {
+  MCLHIP_W_PRODUCT = 0,  /* w = prod_k p_k * pm, the reference's raw product (mc_localization.py:235-240) */
+  MCLHIP_W_LOG = 1       /* w = exp(logw - max logw): same weights after normalisation, no underflow */
+};
+
+/* which CDF walk mclhip_resample uses; both give identical indices */
+enum {
+  MCLHIP_RESAMPLE_SERIAL = 0,   /* one lane replays the reference's loop (mc_localization.py:253-259) */
+  MCLHIP_RESAMPLE_PARALLEL = 1  /* order-exact parallel scan (default) */
+};
+
+/* Library / context ------------------------------------------------------ */
+
+/* ABI version of this header (bumped on incompatible change). */
+int mclhip_abi_version(void);
+
+/* Number of HIP devices visible to the process (no context needed). */
+int mclhip_device_count(void);
+
+/* Replaces MCLocalization.__init__ (mc_localization.py:36-56) for the device
+ * side: creates the context on GPU `device`.  dtype: MCLHIP_F32 / MCLHIP_F64. */
+int mclhip_create(mclhip_ctx** out, int device, int dtype);
+void mclhip_destroy(mclhip_ctx* ctx);
+
+/* Text of the last error on this context (ctx == NULL: last create error). */
+const char* mclhip_last_error(mclhip_ctx* ctx);
+
+/* Map and sensor --------------------------------------------------------- */
+
+/* Replaces make_obstacle_lut (mc_localization.py:61-71) and the free-cell
+ * test's map (mc_localization.py:109).  map: uint8 [H][W]; obstacle == 0,
+ * free == 255.  Kept on the device as two bit planes in 8x8-cell tiles. */
+int mclhip_set_map(mclhip_ctx* ctx, const uint8_t* map, int H, int W, double res_x, double res_y);
+
+/* Replaces the sensor_angles list (mc_localization.py:45-48), the sector
+ * half-angle (mc_localization.py:139) and RangeSensor's constants
+ * (range_sensor.py:5-28).  w4 = {w_hit, w_short, w_max, w_rand}, already
+ * normalised.  angles_deg in degrees, any order, B <= 1024. */
+int mclhip_set_sensor(mclhip_ctx* ctx, const double* angles_deg, int B, double z_max, double sigma_hit,
+                      double lambda_short, const double w4[4], double sector_half_angle_rad);
+
+/* Particle state --------------------------------------------------------- */
+
+/* Replaces assignment of self.X / self.w (mc_localization.py:40-41).
+ * X_aos: [M][3] (x, y, theta); w: [M] or NULL (-> 1/M). */
+int mclhip_set_particles(mclhip_ctx* ctx, const double* X_aos, const double* w, int64_t M);
+
+/* Replaces reads of self.X / self.w.  Any pointer may be NULL.
+ * logw: sum_k log p_k of the last sample (-inf where the motion left the free space). */
+int mclhip_get_particles(mclhip_ctx* ctx, double* X_aos, double* w, double* logw);
+
+int64_t mclhip_num_particles(mclhip_ctx* ctx);
+
+/* Stage entry points (each is one stage of the update, usable on its own) - */
+
+/* Replaces MCLocalization.measure(xt, noise=False) (mc_localization.py:116-171)
+ * over n poses.  ranges: [n][B]; hit_cell (nullable): [n][B] row-major index
+ * of the nearest obstacle cell inside each beam's sector, -1 = none. */
+int mclhip_raycast(mclhip_ctx* ctx, const double* poses_aos, int64_t n, double* ranges, int32_t* hit_cell);
+
+/* Replaces MCLocalization.sample_motion_model_velocity (mc_localization.py:74-114)
+ * over n poses.  noise_ints: [n][3][12] integers in [-1000, 1000], the values
+ * np.random.random_integers(-1000, 1000, 12) would return for the three draws
+ * of each pose (mc_localization.py:20-24, :89-91), or NULL for noise=False.
+ * poses_out [n][3], pm_out [n] (1.0 on a free cell, else 0.0). */
+int mclhip_motion(mclhip_ctx* ctx, const double* poses_aos, int64_t n, double v, double omega, double dt,
+                  const double alpha[6], const int16_t* noise_ints, double* poses_out, double* pm_out);
+
+/* Replaces RangeSensor.compute_px(z, z_true) (range_sensor.py:95-112) over n pairs. */
+int mclhip_compute_px(mclhip_ctx* ctx, const double* z, const double* z_true, int64_t n, double* p_out);
+
+/* Replaces the particle loop of MCLocalization.sample (mc_localization.py:226-240):
+ * motion sample, sector query and beam likelihood for every particle; leaves
+ * the moved poses, w = prod p * pm and logw on the device.
+ * noise_ints: [M][3][12] pre-drawn integers as in mclhip_motion, or NULL to
+ * draw them on the device (counter-based generator keyed by `seed`).
+ * z_meas: [B] measured ranges (self.sensor_ranges, mc_localization.py:224). */
+int mclhip_sample(mclhip_ctx* ctx, double v, double omega, double dt, const double alpha[6],
+                  const int16_t* noise_ints, uint64_t seed, const double* z_meas);
+
+/* Replaces `self.w = self.w / np.sum(self.w)` (mc_localization.py:248); the sum
+ * is accumulated in the order np.sum uses, so it is bit-equal to numpy's.
+ * mode: MCLHIP_W_PRODUCT / MCLHIP_W_LOG.  sum_out nullable. */
+int mclhip_normalise(mclhip_ctx* ctx, int mode, double* sum_out);
+
+/* Replaces the walk of MCLocalization.resample (mc_localization.py:250-262)
+ * after normalisation: r = np.random.rand() * 1/M is drawn by the caller.
+ * Gathers poses and weights (weights are carried, not reset).  An index that
+ * would run past the last particle is clamped to M-1 (the reference raises
+ * IndexError there; 13_fast_slam/fast_slam1.py:426 clamps).
+ * idx_out (nullable): [M] source index of every resampled particle. */
+int mclhip_resample(mclhip_ctx* ctx, double r, int algo, int64_t* idx_out);
+
+/* One whole update = mclhip_sample + mclhip_normalise + mclhip_resample
+ * (mc_localization.py:329-331) without intermediate host synchronisation.
+ * mclhip_step_async returns after enqueueing; mclhip_sync waits. */
+int mclhip_step(mclhip_ctx* ctx, double v, double omega, double dt, const double alpha[6],
+                const int16_t* noise_ints, uint64_t seed, const double* z_meas, int weight_mode, double r);
+int mclhip_step_async(mclhip_ctx* ctx, double v, double omega, double dt, const double alpha[6],
+                      uint64_t seed, const double* z_meas, int weight_mode, double r);
+int mclhip_sync(mclhip_ctx* ctx);
+
+/* Re-load the particle set from a device-resident snapshot taken by
+ * mclhip_snapshot_particles (benchmark helper: every timed step starts from
+ * the same synthetic cloud; a device-to-device copy, no host traffic). */
+int mclhip_snapshot_particles(mclhip_ctx* ctx);
+int mclhip_restore_particles_async(mclhip_ctx* ctx);
+
+/* Measurement ------------------------------------------------------------ */
+
+/* Per-kernel timing with HIP events on the context's own stream.
+ * which: 0 = sector-query + likelihood kernel, 1 = motion kernel,
+ *        2 = normalise + resample + gather kernels together.
+ * Enabling resets the accumulators. */
+int mclhip_timing_enable(mclhip_ctx* ctx, int on);
+int mclhip_timing_get(mclhip_ctx* ctx, int which, int64_t* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCLHIP_H */

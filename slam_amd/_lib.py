@@ -1,0 +1,244 @@
+"""ctypes binding of libmclhip.so (the C ABI declared in include/mclhip.h).
+
+The library is the only compute path of this package: if it cannot be loaded,
+or no GPU is visible when a context is created, the call raises -- there is no
+CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmclhip.so")
+
+F32, F64 = 0, 1
+W_PRODUCT, W_LOG = 0, 1
+RESAMPLE_SERIAL, RESAMPLE_PARALLEL = 0, 1
+
+_lib = None
+
+_dbl_p = C.POINTER(C.c_double)
+_i16_p = C.POINTER(C.c_int16)
+_i32_p = C.POINTER(C.c_int32)
+_i64_p = C.POINTER(C.c_int64)
+_u8_p = C.POINTER(C.c_uint8)
+_ctx_p = C.c_void_p
+
+# name -> (restype, argtypes); every symbol include/mclhip.h declares
+PROTOTYPES = {
+    "mclhip_abi_version": (C.c_int, []),
+    "mclhip_device_count": (C.c_int, []),
+    "mclhip_create": (C.c_int, [C.POINTER(_ctx_p), C.c_int, C.c_int]),
+    "mclhip_destroy": (None, [_ctx_p]),
+    "mclhip_last_error": (C.c_char_p, [_ctx_p]),
+    "mclhip_set_map": (C.c_int, [_ctx_p, _u8_p, C.c_int, C.c_int, C.c_double, C.c_double]),
+    "mclhip_set_sensor": (C.c_int, [_ctx_p, _dbl_p, C.c_int, C.c_double, C.c_double, C.c_double, _dbl_p, C.c_double]),
+    "mclhip_set_particles": (C.c_int, [_ctx_p, _dbl_p, _dbl_p, C.c_int64]),
+    "mclhip_get_particles": (C.c_int, [_ctx_p, _dbl_p, _dbl_p, _dbl_p]),
+    "mclhip_num_particles": (C.c_int64, [_ctx_p]),
+    "mclhip_raycast": (C.c_int, [_ctx_p, _dbl_p, C.c_int64, _dbl_p, _i32_p]),
+    "mclhip_motion": (C.c_int, [_ctx_p, _dbl_p, C.c_int64, C.c_double, C.c_double, C.c_double, _dbl_p, _i16_p,
+                                _dbl_p, _dbl_p]),
+    "mclhip_compute_px": (C.c_int, [_ctx_p, _dbl_p, _dbl_p, C.c_int64, _dbl_p]),
+    "mclhip_sample": (C.c_int, [_ctx_p, C.c_double, C.c_double, C.c_double, _dbl_p, _i16_p, C.c_uint64, _dbl_p]),
+    "mclhip_normalise": (C.c_int, [_ctx_p, C.c_int, _dbl_p]),
+    "mclhip_resample": (C.c_int, [_ctx_p, C.c_double, C.c_int, _i64_p]),
+    "mclhip_step": (C.c_int, [_ctx_p, C.c_double, C.c_double, C.c_double, _dbl_p, _i16_p, C.c_uint64, _dbl_p,
+                              C.c_int, C.c_double]),
+    "mclhip_step_async": (C.c_int, [_ctx_p, C.c_double, C.c_double, C.c_double, _dbl_p, C.c_uint64, _dbl_p, C.c_int,
+                                    C.c_double]),
+    "mclhip_sync": (C.c_int, [_ctx_p]),
+    "mclhip_snapshot_particles": (C.c_int, [_ctx_p]),
+    "mclhip_restore_particles_async": (C.c_int, [_ctx_p]),
+    "mclhip_timing_enable": (C.c_int, [_ctx_p, C.c_int]),
+    "mclhip_timing_get": (C.c_int, [_ctx_p, C.c_int, _i64_p, _dbl_p]),
+}
+
+
+class MclHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libmclhip.so and bind every prototype.  Raises if the file or a symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MclHipError("libmclhip.so is not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "or `make -C slam_amd/csrc`" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError names the missing symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _p(a, typ):
+    return None if a is None else a.ctypes.data_as(typ)
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != shape:
+        raise ValueError("expected shape %r, got %r" % (shape, a.shape))
+    return a
+
+
+class Context:
+    """One GPU context (wraps mclhip_ctx*)."""
+
+    def __init__(self, device=0, dtype=F64):
+        self.lib = load()
+        h = _ctx_p()
+        rc = self.lib.mclhip_create(C.byref(h), int(device), int(dtype))
+        if rc != 0:
+            raise MclHipError("mclhip_create failed (%d): %s" % (rc, self.lib.mclhip_last_error(None).decode()))
+        self.h = h
+        self.dtype = dtype
+        self.B = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mclhip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise MclHipError("%s failed (%d): %s" % (what, rc, self.lib.mclhip_last_error(self.h).decode()))
+
+    # map / sensor ---------------------------------------------------------
+    def set_map(self, grid, res_x, res_y):
+        g = np.ascontiguousarray(grid, dtype=np.uint8)
+        if g.ndim != 2:
+            raise ValueError("map must be 2-D uint8")
+        self._ck(self.lib.mclhip_set_map(self.h, _p(g, _u8_p), g.shape[0], g.shape[1], float(res_x), float(res_y)),
+                 "mclhip_set_map")
+
+    def set_sensor(self, angles_deg, z_max, sigma_hit, lambda_short, w4, half_angle):
+        a = _f64(angles_deg)
+        w = _f64(w4, (4,))
+        self._ck(self.lib.mclhip_set_sensor(self.h, _p(a, _dbl_p), len(a), float(z_max), float(sigma_hit),
+                                            float(lambda_short), _p(w, _dbl_p), float(half_angle)),
+                 "mclhip_set_sensor")
+        self.B = len(a)
+
+    # particles ------------------------------------------------------------
+    def set_particles(self, X, w=None):
+        X = _f64(X)
+        if X.ndim != 2 or X.shape[1] != 3:
+            raise ValueError("X must be [M,3]")
+        wv = None if w is None else _f64(w, (X.shape[0],))
+        self._ck(self.lib.mclhip_set_particles(self.h, _p(X, _dbl_p), _p(wv, _dbl_p), X.shape[0]),
+                 "mclhip_set_particles")
+
+    def num_particles(self):
+        return int(self.lib.mclhip_num_particles(self.h))
+
+    def get_particles(self, want_X=True, want_w=True, want_logw=False):
+        M = self.num_particles()
+        X = np.empty((M, 3)) if want_X else None
+        w = np.empty(M) if want_w else None
+        lw = np.empty(M) if want_logw else None
+        self._ck(self.lib.mclhip_get_particles(self.h, _p(X, _dbl_p), _p(w, _dbl_p), _p(lw, _dbl_p)),
+                 "mclhip_get_particles")
+        return X, w, lw
+
+    # stages -----------------------------------------------------------------
+    def raycast(self, poses, want_hits=True):
+        P = _f64(poses).reshape(-1, 3)
+        n = len(P)
+        R = np.empty((n, self.B))
+        Hc = np.empty((n, self.B), np.int32) if want_hits else None
+        self._ck(self.lib.mclhip_raycast(self.h, _p(P, _dbl_p), n, _p(R, _dbl_p), _p(Hc, _i32_p)), "mclhip_raycast")
+        return R, Hc
+
+    def motion(self, poses, v, omega, dt, alpha, noise_ints=None):
+        P = _f64(poses).reshape(-1, 3)
+        n = len(P)
+        al = _f64(alpha, (6,))
+        nz = None
+        if noise_ints is not None:
+            nz = np.ascontiguousarray(noise_ints, dtype=np.int16)
+            if nz.shape != (n, 3, 12):
+                raise ValueError("noise_ints must be [n,3,12]")
+        out = np.empty((n, 3))
+        pm = np.empty(n)
+        self._ck(self.lib.mclhip_motion(self.h, _p(P, _dbl_p), n, float(v), float(omega), float(dt), _p(al, _dbl_p),
+                                        _p(nz, _i16_p), _p(out, _dbl_p), _p(pm, _dbl_p)), "mclhip_motion")
+        return out, pm
+
+    def compute_px(self, z, z_true):
+        z, zt = np.broadcast_arrays(np.asarray(z, np.float64), np.asarray(z_true, np.float64))
+        shape = z.shape
+        z = np.ascontiguousarray(z).ravel()
+        zt = np.ascontiguousarray(zt).ravel()
+        out = np.empty(len(z))
+        self._ck(self.lib.mclhip_compute_px(self.h, _p(z, _dbl_p), _p(zt, _dbl_p), len(z), _p(out, _dbl_p)),
+                 "mclhip_compute_px")
+        return out.reshape(shape)
+
+    def _noise(self, noise_ints):
+        if noise_ints is None:
+            return None
+        nz = np.ascontiguousarray(noise_ints, dtype=np.int16)
+        if nz.shape != (self.num_particles(), 3, 12):
+            raise ValueError("noise_ints must be [M,3,12]")
+        return nz
+
+    def sample(self, v, omega, dt, alpha, z_meas, noise_ints=None, seed=0):
+        al = _f64(alpha, (6,))
+        zm = _f64(z_meas, (self.B,))
+        nz = self._noise(noise_ints)
+        self._ck(self.lib.mclhip_sample(self.h, float(v), float(omega), float(dt), _p(al, _dbl_p), _p(nz, _i16_p),
+                                        int(seed), _p(zm, _dbl_p)), "mclhip_sample")
+
+    def normalise(self, mode=W_PRODUCT):
+        s = C.c_double(0.0)
+        self._ck(self.lib.mclhip_normalise(self.h, int(mode), C.byref(s)), "mclhip_normalise")
+        return s.value
+
+    def resample(self, r, algo=RESAMPLE_PARALLEL, want_idx=True):
+        idx = np.empty(self.num_particles(), np.int64) if want_idx else None
+        self._ck(self.lib.mclhip_resample(self.h, float(r), int(algo), _p(idx, _i64_p)), "mclhip_resample")
+        return idx
+
+    def step(self, v, omega, dt, alpha, z_meas, r, noise_ints=None, seed=0, weight_mode=W_PRODUCT, wait=True):
+        al = _f64(alpha, (6,))
+        zm = _f64(z_meas, (self.B,))
+        if wait:
+            nz = self._noise(noise_ints)
+            self._ck(self.lib.mclhip_step(self.h, float(v), float(omega), float(dt), _p(al, _dbl_p), _p(nz, _i16_p),
+                                          int(seed), _p(zm, _dbl_p), int(weight_mode), float(r)), "mclhip_step")
+        else:
+            if noise_ints is not None:
+                raise ValueError("the asynchronous step draws its noise on the device")
+            self._ck(self.lib.mclhip_step_async(self.h, float(v), float(omega), float(dt), _p(al, _dbl_p), int(seed),
+                                                _p(zm, _dbl_p), int(weight_mode), float(r)), "mclhip_step_async")
+
+    def sync(self):
+        self._ck(self.lib.mclhip_sync(self.h), "mclhip_sync")
+
+    def snapshot_particles(self):
+        self._ck(self.lib.mclhip_snapshot_particles(self.h), "mclhip_snapshot_particles")
+
+    def restore_particles_async(self):
+        self._ck(self.lib.mclhip_restore_particles_async(self.h), "mclhip_restore_particles_async")
+
+    def timing_enable(self, on=True):
+        self._ck(self.lib.mclhip_timing_enable(self.h, 1 if on else 0), "mclhip_timing_enable")
+
+    def timing_get(self, which):
+        n = C.c_int64(0)
+        ms = C.c_double(0.0)
+        self._ck(self.lib.mclhip_timing_get(self.h, int(which), C.byref(n), C.byref(ms)), "mclhip_timing_get")
+        return n.value, ms.value

@@ -1,0 +1,560 @@
+// C ABI of libmclhip.so (declared in include/mclhip.h): argument checking, host
+// <-> device staging and the order in which the stage kernels are enqueued.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "mclhip_internal.h"
+
+namespace mcl {
+
+static thread_local std::string g_create_err;
+
+int fail(mclhip_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg; else g_create_err = msg;
+  return code;
+}
+
+size_t irr_record_bytes();
+size_t run_base_bytes();
+size_t kf_bytes();
+
+RayParams make_ray_params(const mclhip_ctx* c) {
+  RayParams P;
+  P.obst = c->obst;
+  P.TW = c->TW; P.TH = c->TH; P.W = c->W; P.H = c->H;
+  P.res_xf = (float)c->res_x; P.res_yf = (float)c->res_y;
+  P.res_x = c->res_x; P.res_y = c->res_y;
+  P.z_max = c->z_max;
+  P.r2max = std::pow(c->z_max, 2.0);  // max_sensor_range**2 (mc_localization.py:127)
+  P.B = c->B; P.NB = c->NB;
+  P.tab_sorted = c->tab_sorted; P.tab_orig = c->tab_orig; P.perm = c->perm; P.lut = c->lut;
+  P.ts_min = c->ts_min; P.ts_max = c->ts_max; P.inv_bw = c->inv_bw;
+  P.half = c->half;
+  P.two_pi_lo = M_PI * 2 - c->half;  // mc_localization.py:149
+  P.two_pi_hi = M_PI * 2 + c->half;
+  P.zt = c->zt; P.etalam = c->etalam;
+  P.sigma2 = std::pow(c->sigma, 2.0);                    // s_hit**2 (range_sensor.py:37)
+  P.c_hit = 1 / std::sqrt(2 * M_PI * P.sigma2);          // 1/np.sqrt(2*np.pi*s_hit**2)
+  P.lambda = c->lambda;
+  P.w_hit = c->w4[0]; P.w_short = c->w4[1]; P.w_max = c->w4[2]; P.w_rand = c->w4[3];
+  P.p_rand = 1 / c->z_max;                               // range_sensor.py:64
+  return P;
+}
+
+static size_t esize(const mclhip_ctx* c) { return c->dtype == MCLHIP_F32 ? sizeof(float) : sizeof(double); }
+
+template <typename P>
+static int dev_alloc(mclhip_ctx* c, P** p, size_t bytes) {
+  if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (bytes == 0) bytes = 16;
+  MCL_HIP(c, hipMalloc((void**)p, bytes));
+  return MCLHIP_OK;
+}
+
+#define MCL_TRY(expr) do { int rc__ = (expr); if (rc__ != MCLHIP_OK) return rc__; } while (0)
+
+static int ensure_capacity(mclhip_ctx* c, int64_t M) {
+  if (M <= c->cap) return MCLHIP_OK;
+  const size_t es = esize(c);
+  for (int b = 0; b < 2; ++b) {
+    MCL_TRY(dev_alloc(c, &c->px[b], M * es));
+    MCL_TRY(dev_alloc(c, &c->py[b], M * es));
+    MCL_TRY(dev_alloc(c, &c->pth[b], M * es));
+    MCL_TRY(dev_alloc(c, &c->w[b], M * sizeof(double)));
+  }
+  MCL_TRY(dev_alloc(c, &c->logw, M * sizeof(double)));
+  MCL_TRY(dev_alloc(c, &c->pm, M));
+  const int64_t nchunks = (M + kSumChunk - 1) / kSumChunk;
+  const int64_t ntile = (M + kScanTile - 1) / kScanTile;
+  MCL_TRY(dev_alloc(c, &c->chunk_sums, nchunks * sizeof(double)));
+  MCL_TRY(dev_alloc(c, &c->cdf_approx, M * sizeof(double)));
+  MCL_TRY(dev_alloc(c, &c->cdf_exact, M * sizeof(double)));
+  MCL_TRY(dev_alloc(c, &c->kscan, M * sizeof(uint64_t)));
+  MCL_TRY(dev_alloc(c, &c->fscan, M * sizeof(uint32_t)));
+  MCL_TRY(dev_alloc(c, &c->blk_a, std::max<int64_t>(ntile, 1024) * sizeof(double)));
+  MCL_TRY(dev_alloc(c, &c->blk_b, ntile * kf_bytes()));
+  MCL_TRY(dev_alloc(c, &c->irr, M * irr_record_bytes()));
+  MCL_TRY(dev_alloc(c, &c->bases, M * run_base_bytes()));
+  MCL_TRY(dev_alloc(c, &c->idx, M * sizeof(int64_t)));
+  if (c->noise) { (void)hipFree(c->noise); c->noise = nullptr; }
+  c->cap = M;
+  return MCLHIP_OK;
+}
+
+static int use(mclhip_ctx* c) {
+  if (!c) return MCLHIP_E_ARG;
+  MCL_HIP(c, hipSetDevice(c->device));
+  return MCLHIP_OK;
+}
+
+// timing: events are recorded around kernel groups and read back after the
+// stream has been synchronised
+static void span_begin(mclhip_ctx* c, std::vector<mclhip_ctx::Span>& v, int which) {
+  if (!c->timing) return;
+  mclhip_ctx::Span s; s.which = which;
+  (void)hipEventCreate(&s.a); (void)hipEventCreate(&s.b);
+  (void)hipEventRecord(s.a, c->stream);
+  v.push_back(s);
+}
+static void span_end(mclhip_ctx* c, std::vector<mclhip_ctx::Span>& v) {
+  if (!c->timing || v.empty()) return;
+  (void)hipEventRecord(v.back().b, c->stream);
+}
+static void span_collect(mclhip_ctx* c, std::vector<mclhip_ctx::Span>& v) {
+  for (auto& s : v) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { c->t_ms[s.which] += ms; c->t_launch[s.which] += 1; }
+    (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b);
+  }
+  v.clear();
+}
+
+static MotionParams make_motion_params(const mclhip_ctx* c, double v, double omega, double dt, const double* alpha,
+                                       int noise_mode, uint64_t seed) {
+  MotionParams mp;
+  mp.v = v; mp.omega = omega; mp.dt = dt;
+  // b = alpha_i*|v| + alpha_j*|w| ; sample(b) = b/6.0 * sum  (mc_localization.py:24, :89-91)
+  mp.c1 = (alpha[0] * std::fabs(v) + alpha[1] * std::fabs(omega)) / 6.0;
+  mp.c2 = (alpha[2] * std::fabs(v) + alpha[3] * std::fabs(omega)) / 6.0;
+  mp.c3 = (alpha[4] * std::fabs(v) + alpha[5] * std::fabs(omega)) / 6.0;
+  mp.res_x = c->res_x; mp.res_y = c->res_y;
+  mp.freeb = c->freeb;
+  mp.TW = c->TW; mp.TH = c->TH; mp.W = c->W; mp.H = c->H;
+  mp.noise_mode = noise_mode;
+  mp.seed = seed;
+  return mp;
+}
+
+static int need(mclhip_ctx* c, bool map, bool sensor, bool particles) {
+  if (map && !c->obst) return fail(c, MCLHIP_E_STATE, "no map: call mclhip_set_map first");
+  if (sensor && c->B == 0) return fail(c, MCLHIP_E_STATE, "no sensor: call mclhip_set_sensor first");
+  if (particles && c->M == 0) return fail(c, MCLHIP_E_STATE, "no particles: call mclhip_set_particles first");
+  return MCLHIP_OK;
+}
+
+// enqueue motion + sector query + likelihood for the live particle set
+static int enqueue_sample(mclhip_ctx* c, double v, double omega, double dt, const double* alpha, int noise_mode,
+                          uint64_t seed, std::vector<mclhip_ctx::Span>& spans, bool want_product) {
+  MCL_TRY(launch_beam_table(c));
+  MotionParams mp = make_motion_params(c, v, omega, dt, alpha, noise_mode, seed);
+  const int a = c->cur;
+  span_begin(c, spans, 1);
+  MCL_TRY(launch_motion(c, c->px[a], c->py[a], c->pth[a], c->pm, c->M, mp, c->noise, c->dtype));
+  span_end(c, spans);
+  span_begin(c, spans, 0);
+  // the raw product is only formed when somebody will read it: it costs one dependent multiply per beam
+  MCL_TRY(launch_raycast(c, c->px[a], c->py[a], c->pth[a], c->pm, c->M, c->dtype, want_product ? c->w[a] : nullptr,
+                         c->logw, nullptr, nullptr));
+  span_end(c, spans);
+  return MCLHIP_OK;
+}
+
+static int upload_zmeas(mclhip_ctx* c, const double* z_meas) {
+  if (!z_meas) return fail(c, MCLHIP_E_ARG, "z_meas is NULL");
+  MCL_HIP(c, hipMemcpyAsync(c->zmeas_stage, z_meas, c->B * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  return MCLHIP_OK;
+}
+
+static int upload_noise(mclhip_ctx* c, const int16_t* noise_ints) {
+  const size_t bytes = (size_t)c->M * 36 * sizeof(int16_t);
+  if (!c->noise) MCL_TRY(dev_alloc(c, &c->noise, (size_t)c->cap * 36 * sizeof(int16_t)));
+  MCL_HIP(c, hipMemcpyAsync(c->noise, noise_ints, bytes, hipMemcpyHostToDevice, c->stream));
+  return MCLHIP_OK;
+}
+
+}  // namespace mcl
+
+using namespace mcl;
+
+extern "C" {
+
+int mclhip_abi_version(void) { return 1; }
+
+int mclhip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int mclhip_create(mclhip_ctx** out, int device, int dtype) {
+  if (!out) return fail(nullptr, MCLHIP_E_ARG, "out is NULL");
+  *out = nullptr;
+  if (dtype != MCLHIP_F32 && dtype != MCLHIP_F64) return fail(nullptr, MCLHIP_E_ARG, "dtype must be 0 (f32) or 1 (f64)");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0)
+    return fail(nullptr, MCLHIP_E_HIP, std::string("no HIP device available: ") + hipGetErrorString(e));
+  if (device < 0 || device >= n) return fail(nullptr, MCLHIP_E_ARG, "device index out of range");
+  mclhip_ctx* c = new mclhip_ctx();
+  c->device = device;
+  c->dtype = dtype;
+  e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->scal, 8 * sizeof(double));
+  if (e != hipSuccess) {
+    fail(nullptr, MCLHIP_E_HIP, std::string("context set-up failed: ") + hipGetErrorString(e));
+    delete c;
+    return MCLHIP_E_HIP;
+  }
+  *out = c;
+  return MCLHIP_OK;
+}
+
+void mclhip_destroy(mclhip_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  void* ptrs[] = {c->obst, c->freeb, c->tab_sorted, c->tab_orig, c->perm, c->lut, c->zt, c->etalam, c->zmeas_stage,
+                  c->px[0], c->px[1], c->py[0], c->py[1], c->pth[0], c->pth[1], c->w[0], c->w[1], c->logw, c->pm,
+                  c->sx, c->sy, c->sth, c->sw, c->chunk_sums, c->scal, c->cdf_approx, c->cdf_exact, c->kscan,
+                  c->fscan, c->blk_a, c->blk_b, c->irr, c->bases, c->idx, c->noise, c->counters};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* mclhip_last_error(mclhip_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+int mclhip_set_map(mclhip_ctx* c, const uint8_t* map, int H, int W, double res_x, double res_y) {
+  MCL_TRY(use(c));
+  if (!map || H <= 0 || W <= 0) return fail(c, MCLHIP_E_ARG, "map is NULL or empty");
+  if (H > 65535 || W > 65535) return fail(c, MCLHIP_E_LIMIT, "map sides are limited to 65535 cells");
+  if (!(res_x > 0) || !(res_y > 0)) return fail(c, MCLHIP_E_ARG, "cell size must be positive");
+  c->H = H; c->W = W; c->TH = (H + 7) / 8; c->TW = (W + 7) / 8;
+  c->res_x = res_x; c->res_y = res_y;
+  const size_t nt = (size_t)c->TH * c->TW;
+  MCL_TRY(dev_alloc(c, &c->obst, nt * sizeof(uint64_t)));
+  MCL_TRY(dev_alloc(c, &c->freeb, nt * sizeof(uint64_t)));
+  uint8_t* d_map = nullptr;
+  MCL_HIP(c, hipMalloc((void**)&d_map, (size_t)H * W));
+  hipError_t e = hipMemcpyAsync(d_map, map, (size_t)H * W, hipMemcpyHostToDevice, c->stream);
+  int rc = MCLHIP_OK;
+  if (e == hipSuccess) rc = launch_build_tiles(c, d_map);
+  hipError_t e2 = hipStreamSynchronize(c->stream);
+  (void)hipFree(d_map);
+  if (e != hipSuccess) return fail(c, MCLHIP_E_HIP, std::string("map upload: ") + hipGetErrorString(e));
+  if (rc != MCLHIP_OK) return rc;
+  if (e2 != hipSuccess) return fail(c, MCLHIP_E_HIP, std::string("map tiling: ") + hipGetErrorString(e2));
+  return MCLHIP_OK;
+}
+
+int mclhip_set_sensor(mclhip_ctx* c, const double* angles_deg, int B, double z_max, double sigma_hit,
+                      double lambda_short, const double w4[4], double half) {
+  MCL_TRY(use(c));
+  if (!angles_deg || !w4 || B <= 0) return fail(c, MCLHIP_E_ARG, "angles/w4 NULL or B <= 0");
+  if (B > kMaxBeams) return fail(c, MCLHIP_E_LIMIT, "at most 1024 beams");
+  if (!(z_max > 0) || !(sigma_hit > 0) || !(half >= 0)) return fail(c, MCLHIP_E_ARG, "bad sensor constants");
+  for (int k = 0; k < B; ++k)
+    if (!std::isfinite(angles_deg[k])) return fail(c, MCLHIP_E_ARG, "beam angles must be finite");
+  c->B = B; c->z_max = z_max; c->sigma = sigma_hit; c->lambda = lambda_short; c->half = half;
+  for (int i = 0; i < 4; ++i) c->w4[i] = w4[i];
+  std::vector<double> tab(B), ts(B);
+  for (int k = 0; k < B; ++k) tab[k] = angles_deg[k] * M_PI / 180.0;  // angle*np.pi/180.0 (mc_localization.py:143)
+  std::vector<uint16_t> perm(B);
+  std::iota(perm.begin(), perm.end(), 0);
+  std::stable_sort(perm.begin(), perm.end(), [&](uint16_t a, uint16_t b) { return tab[a] < tab[b]; });
+  for (int k = 0; k < B; ++k) ts[k] = tab[perm[k]];
+  int NB = 1;
+  while (NB < 2 * B) NB <<= 1;
+  c->NB = NB;
+  c->ts_min = ts.front(); c->ts_max = ts.back();
+  const double span = c->ts_max - c->ts_min;
+  const double bw = span / NB;
+  c->inv_bw = (span > 0) ? 1.0 / bw : 0.0;
+  std::vector<uint16_t> lut(NB);
+  for (int b = 0; b < NB; ++b) {
+    const double edge = c->ts_min + b * bw;
+    lut[b] = (uint16_t)(std::lower_bound(ts.begin(), ts.end(), edge) - ts.begin());
+  }
+  MCL_TRY(dev_alloc(c, &c->tab_sorted, B * sizeof(double)));
+  MCL_TRY(dev_alloc(c, &c->tab_orig, B * sizeof(double)));
+  MCL_TRY(dev_alloc(c, &c->perm, B * sizeof(uint16_t)));
+  MCL_TRY(dev_alloc(c, &c->lut, NB * sizeof(uint16_t)));
+  MCL_TRY(dev_alloc(c, &c->zt, B * sizeof(double)));
+  MCL_TRY(dev_alloc(c, &c->etalam, B * sizeof(double)));
+  MCL_TRY(dev_alloc(c, &c->zmeas_stage, B * sizeof(double)));
+  MCL_HIP(c, hipMemcpy(c->tab_sorted, ts.data(), B * sizeof(double), hipMemcpyHostToDevice));
+  MCL_HIP(c, hipMemcpy(c->tab_orig, tab.data(), B * sizeof(double), hipMemcpyHostToDevice));
+  MCL_HIP(c, hipMemcpy(c->perm, perm.data(), B * sizeof(uint16_t), hipMemcpyHostToDevice));
+  MCL_HIP(c, hipMemcpy(c->lut, lut.data(), NB * sizeof(uint16_t), hipMemcpyHostToDevice));
+  MCL_HIP(c, hipMemset(c->zt, 0, B * sizeof(double)));
+  MCL_HIP(c, hipMemset(c->etalam, 0, B * sizeof(double)));
+  return MCLHIP_OK;
+}
+
+int mclhip_set_particles(mclhip_ctx* c, const double* X, const double* w, int64_t M) {
+  MCL_TRY(use(c));
+  if (!X || M <= 0) return fail(c, MCLHIP_E_ARG, "X is NULL or M <= 0");
+  if (M > ((int64_t)1 << 31)) return fail(c, MCLHIP_E_LIMIT, "at most 2^31 particles per context");
+  MCL_TRY(ensure_capacity(c, M));
+  c->M = M;
+  c->cur = 0;
+  const size_t es = esize(c);
+  std::vector<unsigned char> hx(M * es), hy(M * es), ht(M * es);
+  if (c->dtype == MCLHIP_F32) {
+    float* fx = (float*)hx.data(); float* fy = (float*)hy.data(); float* ft = (float*)ht.data();
+    for (int64_t i = 0; i < M; ++i) { fx[i] = (float)X[3 * i]; fy[i] = (float)X[3 * i + 1]; ft[i] = (float)X[3 * i + 2]; }
+  } else {
+    double* fx = (double*)hx.data(); double* fy = (double*)hy.data(); double* ft = (double*)ht.data();
+    for (int64_t i = 0; i < M; ++i) { fx[i] = X[3 * i]; fy[i] = X[3 * i + 1]; ft[i] = X[3 * i + 2]; }
+  }
+  MCL_HIP(c, hipMemcpy(c->px[0], hx.data(), M * es, hipMemcpyHostToDevice));
+  MCL_HIP(c, hipMemcpy(c->py[0], hy.data(), M * es, hipMemcpyHostToDevice));
+  MCL_HIP(c, hipMemcpy(c->pth[0], ht.data(), M * es, hipMemcpyHostToDevice));
+  std::vector<double> hw;
+  if (!w) { hw.assign(M, 1.0 / (double)M); w = hw.data(); }  // np.ones(M)/M (mc_localization.py:41)
+  MCL_HIP(c, hipMemcpy(c->w[0], w, M * sizeof(double), hipMemcpyHostToDevice));
+  std::vector<double> z(M, 0.0);
+  MCL_HIP(c, hipMemcpy(c->logw, z.data(), M * sizeof(double), hipMemcpyHostToDevice));
+  return MCLHIP_OK;
+}
+
+int mclhip_get_particles(mclhip_ctx* c, double* X, double* w, double* logw) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, false, false, true));
+  MCL_HIP(c, hipStreamSynchronize(c->stream));
+  const int64_t M = c->M;
+  const int a = c->cur;
+  if (X) {
+    const size_t es = esize(c);
+    std::vector<unsigned char> hx(M * es), hy(M * es), ht(M * es);
+    MCL_HIP(c, hipMemcpy(hx.data(), c->px[a], M * es, hipMemcpyDeviceToHost));
+    MCL_HIP(c, hipMemcpy(hy.data(), c->py[a], M * es, hipMemcpyDeviceToHost));
+    MCL_HIP(c, hipMemcpy(ht.data(), c->pth[a], M * es, hipMemcpyDeviceToHost));
+    if (c->dtype == MCLHIP_F32) {
+      const float* fx = (const float*)hx.data(); const float* fy = (const float*)hy.data(); const float* ft = (const float*)ht.data();
+      for (int64_t i = 0; i < M; ++i) { X[3 * i] = fx[i]; X[3 * i + 1] = fy[i]; X[3 * i + 2] = ft[i]; }
+    } else {
+      const double* fx = (const double*)hx.data(); const double* fy = (const double*)hy.data(); const double* ft = (const double*)ht.data();
+      for (int64_t i = 0; i < M; ++i) { X[3 * i] = fx[i]; X[3 * i + 1] = fy[i]; X[3 * i + 2] = ft[i]; }
+    }
+  }
+  if (w) MCL_HIP(c, hipMemcpy(w, c->w[a], M * sizeof(double), hipMemcpyDeviceToHost));
+  if (logw) MCL_HIP(c, hipMemcpy(logw, c->logw, M * sizeof(double), hipMemcpyDeviceToHost));
+  return MCLHIP_OK;
+}
+
+int64_t mclhip_num_particles(mclhip_ctx* c) { return c ? c->M : 0; }
+
+int mclhip_raycast(mclhip_ctx* c, const double* poses, int64_t n, double* ranges, int32_t* hit_cell) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, true, true, false));
+  if (!poses || !ranges || n <= 0) return fail(c, MCLHIP_E_ARG, "poses/ranges NULL or n <= 0");
+  const int B = c->B;
+  std::vector<double> hx(n), hy(n), ht(n);
+  for (int64_t i = 0; i < n; ++i) { hx[i] = poses[3 * i]; hy[i] = poses[3 * i + 1]; ht[i] = poses[3 * i + 2]; }
+  double *dx = nullptr, *dy = nullptr, *dt = nullptr, *dr = nullptr;
+  int32_t* dh = nullptr;
+  int rc = MCLHIP_OK;
+  hipError_t e = hipMalloc((void**)&dx, n * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&dy, n * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&dt, n * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&dr, (size_t)n * B * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&dh, (size_t)n * B * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMemcpyAsync(dx, hx.data(), n * sizeof(double), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dy, hy.data(), n * sizeof(double), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dt, ht.data(), n * sizeof(double), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) rc = launch_raycast(c, dx, dy, dt, nullptr, n, MCLHIP_F64, nullptr, nullptr, dr, dh);
+  if (e == hipSuccess && rc == MCLHIP_OK) e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess && rc == MCLHIP_OK) e = hipMemcpy(ranges, dr, (size_t)n * B * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && rc == MCLHIP_OK && hit_cell)
+    e = hipMemcpy(hit_cell, dh, (size_t)n * B * sizeof(int32_t), hipMemcpyDeviceToHost);
+  (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dt); (void)hipFree(dr); (void)hipFree(dh);
+  if (rc != MCLHIP_OK) return rc;
+  if (e != hipSuccess) return fail(c, MCLHIP_E_HIP, std::string("raycast: ") + hipGetErrorString(e));
+  return MCLHIP_OK;
+}
+
+int mclhip_motion(mclhip_ctx* c, const double* poses, int64_t n, double v, double omega, double dt,
+                  const double alpha[6], const int16_t* noise_ints, double* poses_out, double* pm_out) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, true, false, false));
+  if (!poses || !alpha || !poses_out || n <= 0) return fail(c, MCLHIP_E_ARG, "poses/alpha/poses_out NULL or n <= 0");
+  std::vector<double> hx(n), hy(n), ht(n);
+  for (int64_t i = 0; i < n; ++i) { hx[i] = poses[3 * i]; hy[i] = poses[3 * i + 1]; ht[i] = poses[3 * i + 2]; }
+  double *dx = nullptr, *dy = nullptr, *dth = nullptr;
+  uint8_t* dpm = nullptr;
+  int16_t* dn = nullptr;
+  int rc = MCLHIP_OK;
+  hipError_t e = hipMalloc((void**)&dx, n * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&dy, n * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&dth, n * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&dpm, n);
+  if (e == hipSuccess && noise_ints) e = hipMalloc((void**)&dn, (size_t)n * 36 * sizeof(int16_t));
+  if (e == hipSuccess) e = hipMemcpyAsync(dx, hx.data(), n * sizeof(double), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dy, hy.data(), n * sizeof(double), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dth, ht.data(), n * sizeof(double), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess && noise_ints)
+    e = hipMemcpyAsync(dn, noise_ints, (size_t)n * 36 * sizeof(int16_t), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    MotionParams mp = make_motion_params(c, v, omega, dt, alpha, noise_ints ? 1 : 0, 0);
+    rc = launch_motion(c, dx, dy, dth, dpm, n, mp, dn, MCLHIP_F64);
+  }
+  std::vector<uint8_t> hpm(n);
+  if (e == hipSuccess && rc == MCLHIP_OK) e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess && rc == MCLHIP_OK) e = hipMemcpy(hx.data(), dx, n * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && rc == MCLHIP_OK) e = hipMemcpy(hy.data(), dy, n * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && rc == MCLHIP_OK) e = hipMemcpy(ht.data(), dth, n * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && rc == MCLHIP_OK) e = hipMemcpy(hpm.data(), dpm, n, hipMemcpyDeviceToHost);
+  (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dth); (void)hipFree(dpm); (void)hipFree(dn);
+  if (rc != MCLHIP_OK) return rc;
+  if (e != hipSuccess) return fail(c, MCLHIP_E_HIP, std::string("motion: ") + hipGetErrorString(e));
+  for (int64_t i = 0; i < n; ++i) {
+    poses_out[3 * i] = hx[i]; poses_out[3 * i + 1] = hy[i]; poses_out[3 * i + 2] = ht[i];
+    if (pm_out) pm_out[i] = hpm[i] ? 1.0 : 0.0;
+  }
+  return MCLHIP_OK;
+}
+
+int mclhip_compute_px(mclhip_ctx* c, const double* z, const double* z_true, int64_t n, double* p_out) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, false, true, false));
+  if (!z || !z_true || !p_out || n <= 0) return fail(c, MCLHIP_E_ARG, "z/z_true/p_out NULL or n <= 0");
+  double *dz = nullptr, *dt = nullptr, *dp = nullptr;
+  int rc = MCLHIP_OK;
+  hipError_t e = hipMalloc((void**)&dz, n * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&dt, n * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&dp, n * sizeof(double));
+  if (e == hipSuccess) e = hipMemcpyAsync(dz, z, n * sizeof(double), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dt, z_true, n * sizeof(double), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) rc = launch_compute_px(c, dz, dt, n, dp);
+  if (e == hipSuccess && rc == MCLHIP_OK) e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess && rc == MCLHIP_OK) e = hipMemcpy(p_out, dp, n * sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipFree(dz); (void)hipFree(dt); (void)hipFree(dp);
+  if (rc != MCLHIP_OK) return rc;
+  if (e != hipSuccess) return fail(c, MCLHIP_E_HIP, std::string("compute_px: ") + hipGetErrorString(e));
+  return MCLHIP_OK;
+}
+
+int mclhip_sample(mclhip_ctx* c, double v, double omega, double dt, const double alpha[6], const int16_t* noise_ints,
+                  uint64_t seed, const double* z_meas) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, true, true, true));
+  if (!alpha) return fail(c, MCLHIP_E_ARG, "alpha is NULL");
+  MCL_TRY(upload_zmeas(c, z_meas));
+  if (noise_ints) MCL_TRY(upload_noise(c, noise_ints));
+  std::vector<mclhip_ctx::Span>& spans = c->spans;
+  MCL_TRY(enqueue_sample(c, v, omega, dt, alpha, noise_ints ? 1 : 2, seed, spans, true));
+  MCL_HIP(c, hipStreamSynchronize(c->stream));
+  span_collect(c, spans);
+  return MCLHIP_OK;
+}
+
+int mclhip_normalise(mclhip_ctx* c, int mode, double* sum_out) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, false, false, true));
+  if (mode != MCLHIP_W_PRODUCT && mode != MCLHIP_W_LOG) return fail(c, MCLHIP_E_ARG, "bad weight mode");
+  std::vector<mclhip_ctx::Span>& spans = c->spans;
+  span_begin(c, spans, 2);
+  MCL_TRY(launch_normalise(c, mode));
+  span_end(c, spans);
+  MCL_HIP(c, hipStreamSynchronize(c->stream));
+  span_collect(c, spans);
+  if (sum_out) MCL_HIP(c, hipMemcpy(sum_out, c->scal, sizeof(double), hipMemcpyDeviceToHost));
+  return MCLHIP_OK;
+}
+
+int mclhip_resample(mclhip_ctx* c, double r, int algo, int64_t* idx_out) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, false, false, true));
+  if (algo != MCLHIP_RESAMPLE_SERIAL && algo != MCLHIP_RESAMPLE_PARALLEL) return fail(c, MCLHIP_E_ARG, "bad algo");
+  std::vector<mclhip_ctx::Span>& spans = c->spans;
+  span_begin(c, spans, 2);
+  MCL_TRY(launch_resample(c, r, algo));
+  span_end(c, spans);
+  MCL_HIP(c, hipStreamSynchronize(c->stream));
+  span_collect(c, spans);
+  if (idx_out) MCL_HIP(c, hipMemcpy(idx_out, c->idx, c->M * sizeof(int64_t), hipMemcpyDeviceToHost));
+  return MCLHIP_OK;
+}
+
+static int step_common(mclhip_ctx* c, double v, double omega, double dt, const double alpha[6],
+                       const int16_t* noise_ints, uint64_t seed, const double* z_meas, int weight_mode, double r,
+                       bool wait) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, true, true, true));
+  if (!alpha) return fail(c, MCLHIP_E_ARG, "alpha is NULL");
+  if (weight_mode != MCLHIP_W_PRODUCT && weight_mode != MCLHIP_W_LOG) return fail(c, MCLHIP_E_ARG, "bad weight mode");
+  MCL_TRY(upload_zmeas(c, z_meas));
+  if (noise_ints) MCL_TRY(upload_noise(c, noise_ints));
+  std::vector<mclhip_ctx::Span>& spans = c->spans;
+  MCL_TRY(enqueue_sample(c, v, omega, dt, alpha, noise_ints ? 1 : 2, seed, spans, weight_mode == MCLHIP_W_PRODUCT));
+  span_begin(c, spans, 2);
+  MCL_TRY(launch_normalise(c, weight_mode));
+  MCL_TRY(launch_resample(c, r, MCLHIP_RESAMPLE_PARALLEL));
+  span_end(c, spans);
+  if (wait) {
+    MCL_HIP(c, hipStreamSynchronize(c->stream));
+    span_collect(c, spans);
+  }
+  return MCLHIP_OK;
+}
+
+int mclhip_step(mclhip_ctx* c, double v, double omega, double dt, const double alpha[6], const int16_t* noise_ints,
+                uint64_t seed, const double* z_meas, int weight_mode, double r) {
+  return step_common(c, v, omega, dt, alpha, noise_ints, seed, z_meas, weight_mode, r, true);
+}
+
+int mclhip_step_async(mclhip_ctx* c, double v, double omega, double dt, const double alpha[6], uint64_t seed,
+                      const double* z_meas, int weight_mode, double r) {
+  return step_common(c, v, omega, dt, alpha, nullptr, seed, z_meas, weight_mode, r, false);
+}
+
+int mclhip_sync(mclhip_ctx* c) {
+  MCL_TRY(use(c));
+  MCL_HIP(c, hipStreamSynchronize(c->stream));
+  span_collect(c, c->spans);
+  return MCLHIP_OK;
+}
+
+int mclhip_snapshot_particles(mclhip_ctx* c) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, false, false, true));
+  const size_t es = esize(c);
+  const int64_t M = c->M;
+  MCL_TRY(dev_alloc(c, &c->sx, M * es));
+  MCL_TRY(dev_alloc(c, &c->sy, M * es));
+  MCL_TRY(dev_alloc(c, &c->sth, M * es));
+  MCL_TRY(dev_alloc(c, &c->sw, M * sizeof(double)));
+  const int a = c->cur;
+  MCL_HIP(c, hipMemcpyAsync(c->sx, c->px[a], M * es, hipMemcpyDeviceToDevice, c->stream));
+  MCL_HIP(c, hipMemcpyAsync(c->sy, c->py[a], M * es, hipMemcpyDeviceToDevice, c->stream));
+  MCL_HIP(c, hipMemcpyAsync(c->sth, c->pth[a], M * es, hipMemcpyDeviceToDevice, c->stream));
+  MCL_HIP(c, hipMemcpyAsync(c->sw, c->w[a], M * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  MCL_HIP(c, hipStreamSynchronize(c->stream));
+  c->sM = M;
+  return MCLHIP_OK;
+}
+
+int mclhip_restore_particles_async(mclhip_ctx* c) {
+  MCL_TRY(use(c));
+  if (c->sM == 0 || c->sM != c->M) return fail(c, MCLHIP_E_STATE, "no snapshot of the current particle count");
+  const size_t es = esize(c);
+  const int64_t M = c->M;
+  const int a = c->cur;
+  MCL_HIP(c, hipMemcpyAsync(c->px[a], c->sx, M * es, hipMemcpyDeviceToDevice, c->stream));
+  MCL_HIP(c, hipMemcpyAsync(c->py[a], c->sy, M * es, hipMemcpyDeviceToDevice, c->stream));
+  MCL_HIP(c, hipMemcpyAsync(c->pth[a], c->sth, M * es, hipMemcpyDeviceToDevice, c->stream));
+  MCL_HIP(c, hipMemcpyAsync(c->w[a], c->sw, M * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  return MCLHIP_OK;
+}
+
+int mclhip_timing_enable(mclhip_ctx* c, int on) {
+  if (!c) return MCLHIP_E_ARG;
+  c->timing = on != 0;
+  for (int i = 0; i < 3; ++i) { c->t_launch[i] = 0; c->t_ms[i] = 0; }
+  return MCLHIP_OK;
+}
+
+int mclhip_timing_get(mclhip_ctx* c, int which, int64_t* launches, double* total_ms) {
+  if (!c || which < 0 || which > 2) return MCLHIP_E_ARG;
+  if (launches) *launches = c->t_launch[which];
+  if (total_ms) *total_ms = c->t_ms[which];
+  return MCLHIP_OK;
+}
+
+}  // extern "C"

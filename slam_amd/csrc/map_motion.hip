@@ -1,0 +1,207 @@
+// Map ingestion (bit planes), beam-constant table, velocity motion sampling and
+// the stand-alone beam-mixture kernel.  Compiled with -ffp-contract=off: every
+// float64 expression below is meant to round exactly where the reference's
+// numpy/Python expression rounds.
+#include "mclhip_internal.h"
+
+namespace mcl {
+
+// ---------------------------------------------------------------------------
+// Map -> two bit planes in 8x8 tiles.  Bit (r*8+c) of tile (ty,tx) describes
+// cell (8*ty+r, 8*tx+c).  Obstacle == 0 (mc_localization.py:65), free == 255
+// (mc_localization.py:109); anything else is neither.
+// ---------------------------------------------------------------------------
+__global__ void build_tiles_kernel(const uint8_t* __restrict__ map, int H, int W, int TH, int TW,
+                                   uint64_t* __restrict__ obst, uint64_t* __restrict__ freeb) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= TH * TW) return;
+  int ty = t / TW, tx = t % TW;
+  uint64_t ob = 0, fr = 0;
+  for (int r = 0; r < 8; ++r) {
+    int row = ty * 8 + r;
+    if (row >= H) break;
+    for (int c = 0; c < 8; ++c) {
+      int col = tx * 8 + c;
+      if (col >= W) break;
+      uint8_t v = map[(size_t)row * W + col];
+      uint64_t bit = 1ull << (r * 8 + c);
+      if (v == 0) ob |= bit;
+      if (v == 255) fr |= bit;
+    }
+  }
+  obst[t] = ob;
+  freeb[t] = fr;
+}
+
+int launch_build_tiles(mclhip_ctx* c, const uint8_t* d_map) {
+  int n = c->TH * c->TW;
+  hipLaunchKernelGGL(build_tiles_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_map, c->H, c->W, c->TH,
+                     c->TW, c->obst, c->freeb);
+  MCL_HIP(c, hipGetLastError());
+  return MCLHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Per-beam constants that depend only on the measured range z*_k:
+//   etalam_k = 1/(1 - exp(-lambda*z*_k)) * lambda      (range_sensor.py:49-50)
+// ---------------------------------------------------------------------------
+__global__ void beam_table_kernel(const double* __restrict__ zmeas, int B, double lambda, double* __restrict__ zt,
+                                  double* __restrict__ etalam) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= B) return;
+  double z = zmeas[k];
+  double eta = 1.0 / (1.0 - exp(-lambda * z));
+  zt[k] = z;
+  etalam[k] = eta * lambda;
+}
+
+int launch_beam_table(mclhip_ctx* c) {
+  hipLaunchKernelGGL(beam_table_kernel, dim3((c->B + 63) / 64), dim3(64), 0, c->stream, c->zmeas_stage, c->B,
+                     c->lambda, c->zt, c->etalam);
+  MCL_HIP(c, hipGetLastError());
+  return MCLHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Counter-based generator (Philox 4x32, 10 rounds) for the device-side noise
+// stream: 36 integers uniform on [-1000, 1000] per particle.
+// ---------------------------------------------------------------------------
+__device__ inline void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  uint64_t p0 = (uint64_t)M0 * c[0];
+  uint64_t p1 = (uint64_t)M1 * c[2];
+  uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+  uint32_t n1 = (uint32_t)p1;
+  uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+  uint32_t n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__device__ inline void philox4x32(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+
+// Sum of twelve scaled integers in the order numpy's pairwise reduction uses
+// for n = 12 (mc_localization.py:23-24: `r.sum()`): eight accumulators
+// combined as a tree, then the four remaining terms one by one.
+__device__ inline double sum12(const int* k) {
+  double r[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) r[i] = (double)k[i] * 0.001;
+  double a = (r[0] + r[1]) + (r[2] + r[3]);
+  double b = (r[4] + r[5]) + (r[6] + r[7]);
+  double s = a + b;
+  s = s + r[8];
+  s = s + r[9];
+  s = s + r[10];
+  s = s + r[11];
+  return s;
+}
+
+// Free-cell indicator of mc_localization.py:106-112: int(x/res + 0.5) truncates
+// toward zero; the cell must hold exactly 255.
+__device__ inline bool on_free_cell(double x, double y, const MotionParams& mp) {
+  double fu = x / mp.res_x + 0.5;
+  double fv = y / mp.res_y + 0.5;
+  if (!(fu > -1.0 && fu < (double)mp.W && fv > -1.0 && fv < (double)mp.H)) return false;  // also rejects NaN
+  int u = (int)fu, v = (int)fv;  // C conversion truncates toward zero, like Python's int()
+  if (u < 0 || u >= mp.W || v < 0 || v >= mp.H) return false;
+  uint64_t t = mp.freeb[(size_t)(v >> 3) * mp.TW + (u >> 3)];
+  return (t >> (((v & 7) << 3) | (u & 7))) & 1ull;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void motion_kernel(T* __restrict__ xs, T* __restrict__ ys, T* __restrict__ ths,
+                                                     uint8_t* __restrict__ pm, int64_t n, MotionParams mp,
+                                                     const int16_t* __restrict__ noise) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double x = (double)xs[i], y = (double)ys[i], th = (double)ths[i];
+  double v_hat = mp.v, w_hat = mp.omega, g_hat = 0.0;
+  if (mp.noise_mode != 0) {
+    int k[36];
+    if (mp.noise_mode == 1) {
+      const int16_t* src = noise + i * 36;
+#pragma unroll
+      for (int j = 0; j < 36; ++j) k[j] = (int)src[j];
+    } else {
+#pragma unroll
+      for (int b = 0; b < 9; ++b) {
+        uint32_t ctr[4] = {(uint32_t)i, (uint32_t)((uint64_t)i >> 32), (uint32_t)b, 0x4d434cu};
+        philox4x32(ctr, (uint32_t)mp.seed, (uint32_t)(mp.seed >> 32));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) k[b * 4 + j] = (int)(((uint64_t)ctr[j] * 2001ull) >> 32) - 1000;
+      }
+    }
+    v_hat = mp.v + mp.c1 * sum12(k);          // mc_localization.py:89
+    w_hat = mp.omega + mp.c2 * sum12(k + 12); // :90
+    g_hat = mp.c3 * sum12(k + 24);            // :91
+  }
+  double nx, ny, nt;
+  if (fabs(w_hat) > 0.0) {  // mc_localization.py:97-100
+    double q = v_hat / w_hat;
+    double wd = w_hat * mp.dt;
+    nx = x - q * sin(th) + q * sin(th + wd);
+    ny = y + q * cos(th) - q * cos(th + wd);
+    nt = th + wd + g_hat * mp.dt;
+  } else {  // :101-104
+    nx = x + v_hat * cos(th) * mp.dt;
+    ny = y + v_hat * sin(th) * mp.dt;
+    nt = th + g_hat * mp.dt;
+  }
+  T sx = (T)nx, sy = (T)ny, st = (T)nt;
+  xs[i] = sx;
+  ys[i] = sy;
+  ths[i] = st;
+  pm[i] = on_free_cell((double)sx, (double)sy, mp) ? 1 : 0;
+}
+
+int launch_motion(mclhip_ctx* c, void* x, void* y, void* th, uint8_t* pm, int64_t n, const MotionParams& mp,
+                  const int16_t* d_noise, int dtype) {
+  if (n <= 0) return MCLHIP_OK;
+  dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (dtype == MCLHIP_F32)
+    hipLaunchKernelGGL(motion_kernel<float>, grid, block, 0, c->stream, (float*)x, (float*)y, (float*)th, pm, n, mp,
+                       d_noise);
+  else
+    hipLaunchKernelGGL(motion_kernel<double>, grid, block, 0, c->stream, (double*)x, (double*)y, (double*)th, pm, n,
+                       mp, d_noise);
+  MCL_HIP(c, hipGetLastError());
+  return MCLHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Beam mixture p(z | z*) for explicit (z, z*) pairs (range_sensor.py:95-112).
+// ---------------------------------------------------------------------------
+__global__ void compute_px_kernel(const double* __restrict__ z, const double* __restrict__ zt, int64_t n,
+                                  RayParams P, double* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double x = z[i], t = zt[i];
+  bool in = (0.0 <= x) && (x <= P.z_max);
+  double d = x - t;
+  double p_hit = in ? P.c_hit * exp(-0.5 * (d * d) / P.sigma2) : 0.0;
+  double p_short = 0.0;
+  if (0.0 <= x && x <= t) {
+    double eta = 1.0 / (1.0 - exp(-P.lambda * t));
+    p_short = eta * P.lambda * exp(-P.lambda * x);
+  }
+  double p_max = (fabs(x - P.z_max) < 1e-6) ? 1.0 : 0.0;
+  double p_rand = in ? P.p_rand : 0.0;
+  out[i] = p_hit * P.w_hit + p_short * P.w_short + p_max * P.w_max + p_rand * P.w_rand;
+}
+
+int launch_compute_px(mclhip_ctx* c, const double* z, const double* zt, int64_t n, double* p) {
+  if (n <= 0) return MCLHIP_OK;
+  RayParams P = make_ray_params(c);
+  hipLaunchKernelGGL(compute_px_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, z, zt, n, P, p);
+  MCL_HIP(c, hipGetLastError());
+  return MCLHIP_OK;
+}
+
+}  // namespace mcl

@@ -1,0 +1,140 @@
+// Internal declarations shared by the translation units of libmclhip.so.
+// gfx950 (MI355X) only: 64-lane wavefronts are assumed throughout.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/mclhip.h"
+
+namespace mcl {
+
+constexpr int kWave = 64;
+constexpr int kMaxBeams = 1024;
+constexpr int kSumChunk = 8192;   // numpy reduces float64 vectors chunk by chunk of this size
+constexpr int kScanBlock = 256;   // threads per scan block
+constexpr int kScanItems = 8;     // elements per thread in the scans
+constexpr int kScanTile = kScanBlock * kScanItems;
+
+// Everything the sector-query kernel needs about the map and the sensor.
+struct RayParams {
+  const uint64_t* obst;  // obstacle bit plane, one 64-bit word per 8x8-cell tile, row-major tiles
+  int TW, TH, W, H;
+  float res_xf, res_yf;  // float32 cell size: cell-centre coordinates are float32 products
+  double res_x, res_y;
+  double z_max, r2max;
+  int B, NB;
+  const double* tab_sorted;  // beam angles in radians (deg*pi/180), ascending
+  const double* tab_orig;    // the same, in the caller's beam order
+  const uint16_t* perm;      // sorted position -> caller's beam index
+  const uint16_t* lut;       // bucket -> first sorted position at or after the bucket's lower edge
+  double ts_min, ts_max, inv_bw;
+  double half, two_pi_lo, two_pi_hi;
+  // beam mixture
+  const double* zt;      // measured range per beam
+  const double* etalam;  // eta_short * lambda_short per beam
+  double c_hit;          // 1/sqrt(2*pi*sigma^2)
+  double sigma2;         // sigma^2
+  double lambda;
+  double w_hit, w_short, w_max, w_rand;
+  double p_rand;         // 1/z_max
+};
+
+struct MotionParams {
+  double v, omega, dt;
+  double c1, c2, c3;     // b/6 for the three draws
+  double res_x, res_y;
+  const uint64_t* freeb; // free-cell bit plane, tiled like the obstacle plane
+  int TW, TH, W, H;
+  int noise_mode;        // 0 none, 1 pre-drawn integers, 2 device generator
+  uint64_t seed;
+};
+
+}  // namespace mcl
+
+struct mclhip_ctx {
+  int device = 0;
+  int dtype = MCLHIP_F64;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // map
+  int H = 0, W = 0, TH = 0, TW = 0;
+  double res_x = 0, res_y = 0;
+  uint64_t* obst = nullptr;
+  uint64_t* freeb = nullptr;
+
+  // sensor
+  int B = 0, NB = 0;
+  double z_max = 0, sigma = 0, lambda = 0, w4[4] = {0, 0, 0, 0}, half = 0;
+  double ts_min = 0, ts_max = 0, inv_bw = 0;
+  double* tab_sorted = nullptr;
+  double* tab_orig = nullptr;
+  uint16_t* perm = nullptr;
+  uint16_t* lut = nullptr;
+  double* zt = nullptr;      // [B]
+  double* etalam = nullptr;  // [B]
+  double* zmeas_stage = nullptr;  // [B] staging for z_meas uploads
+
+  // particles (structure of arrays; pose arrays are float or double by dtype)
+  int64_t M = 0, cap = 0;
+  void* px[2] = {nullptr, nullptr};
+  void* py[2] = {nullptr, nullptr};
+  void* pth[2] = {nullptr, nullptr};
+  double* w[2] = {nullptr, nullptr};
+  int cur = 0;               // which of the two buffers holds the live set
+  double* logw = nullptr;
+  uint8_t* pm = nullptr;
+  // snapshot (benchmark helper)
+  void* sx = nullptr; void* sy = nullptr; void* sth = nullptr; double* sw = nullptr; int64_t sM = 0;
+
+  // scratch for normalise / resample
+  double* chunk_sums = nullptr;  // [ceil(M/8192)]
+  double* scal = nullptr;        // [8] device scalars: 0 sum, 1 max logw
+  double* cdf_approx = nullptr;  // [M]
+  double* cdf_exact = nullptr;   // [M]
+  uint64_t* kscan = nullptr;     // [M] integer prefix sums
+  uint32_t* fscan = nullptr;     // [M] irregular-element counts
+  void* blk_a = nullptr;         // block partials (double / u64+u32)
+  void* blk_b = nullptr;
+  void* irr = nullptr;           // irregular-element records
+  void* bases = nullptr;         // run bases
+  int64_t* idx = nullptr;        // [M]
+  int16_t* noise = nullptr;      // [M][3][12] staging for pre-drawn integers
+  uint32_t* counters = nullptr;  // small device counters
+
+  // timing
+  bool timing = false;
+  int64_t t_launch[3] = {0, 0, 0};
+  double t_ms[3] = {0, 0, 0};
+  struct Span { hipEvent_t a, b; int which; };
+  std::vector<Span> spans;   // event pairs recorded but not yet read back
+};
+
+namespace mcl {
+
+// error helpers (api translation unit owns the definitions)
+int fail(mclhip_ctx* c, int code, const std::string& msg);
+#define MCL_HIP(c, expr)                                                              \
+  do {                                                                                \
+    hipError_t e__ = (expr);                                                          \
+    if (e__ != hipSuccess)                                                            \
+      return mcl::fail((c), MCLHIP_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+  } while (0)
+
+// kernels launchers, one per stage; all enqueue on c->stream
+int launch_build_tiles(mclhip_ctx* c, const uint8_t* d_map);
+int launch_beam_table(mclhip_ctx* c);
+int launch_motion(mclhip_ctx* c, void* x, void* y, void* th, uint8_t* pm, int64_t n, const MotionParams& mp,
+                  const int16_t* d_noise, int dtype);
+int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, const uint8_t* pm, int64_t n,
+                   int dtype, double* w_out, double* logw_out, double* ranges_out, int32_t* hits_out);
+int launch_compute_px(mclhip_ctx* c, const double* z, const double* zt, int64_t n, double* p);
+int launch_normalise(mclhip_ctx* c, int mode);
+int launch_resample(mclhip_ctx* c, double r, int algo);
+RayParams make_ray_params(const mclhip_ctx* c);
+
+}  // namespace mcl

@@ -1,0 +1,434 @@
+// Weight normalisation in numpy's summation order, and low-variance resampling
+// whose indices equal those of the reference's strictly sequential float64
+// walk (mc_localization.py:242-262) while being computed in parallel.
+//
+// Compiled with -ffp-contract=off.
+#include "mclhip_internal.h"
+
+namespace mcl {
+
+// ===========================================================================
+// np.sum order.  numpy reduces a contiguous float64 vector in chunks of 8192;
+// inside a chunk it sums pairwise: <8 serial; <=128: eight strided accumulators
+// combined ((0+1)+(2+3))+((4+5)+(6+7)) plus a serial tail; else split at n/2
+// rounded down to a multiple of 8.  Chunk results are added left to right.
+// ===========================================================================
+template <int DEPTH>
+__device__ double pairwise(const double* a, int n) {
+  if (n < 8) {
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s = s + a[i];
+    return s;
+  }
+  if (n <= 128) {
+    double r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] = r[j] + a[i + j];
+    }
+    double s = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) s = s + a[i];
+    return s;
+  }
+  int h = n / 2;
+  h -= h % 8;
+  if constexpr (DEPTH > 0) {
+    return pairwise<DEPTH - 1>(a, h) + pairwise<DEPTH - 1>(a + h, n - h);
+  } else {
+    return 0.0;  // unreachable for n <= 8192
+  }
+}
+
+// One block of 512 threads per 8192-element chunk.  Thread (leaf, j) owns
+// accumulator j of a 128-element leaf; xor-butterflies over lane bits 0..2
+// combine the eight accumulators as ((0+1)+(2+3))+((4+5)+(6+7)), bits 3..5
+// combine the eight leaves a wave holds, and the eight wave results are
+// combined in the same left/right order -- numpy's recursion tree for n = 8192.
+__global__ __launch_bounds__(512) void chunk_sum_kernel(const double* __restrict__ w, int64_t n,
+                                                        double* __restrict__ chunk_sums) {
+  __shared__ double wave_sum[8];
+  const int64_t base = (int64_t)blockIdx.x * kSumChunk;
+  const int cnt = (int)((n - base) < kSumChunk ? (n - base) : kSumChunk);
+  if (cnt == kSumChunk) {
+    const int leaf = threadIdx.x >> 3, j = threadIdx.x & 7;
+    const double* a = w + base + leaf * 128 + j;
+    double r = a[0];
+#pragma unroll
+    for (int g = 1; g < 16; ++g) r = r + a[8 * g];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) r = r + __shfl_xor(r, d, 64);
+    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = r;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      chunk_sums[blockIdx.x] = ((wave_sum[0] + wave_sum[1]) + (wave_sum[2] + wave_sum[3])) +
+                               ((wave_sum[4] + wave_sum[5]) + (wave_sum[6] + wave_sum[7]));
+  } else {
+    if (threadIdx.x == 0) chunk_sums[blockIdx.x] = pairwise<7>(w + base, cnt);
+  }
+}
+
+__global__ void total_sum_kernel(const double* __restrict__ chunk_sums, int nchunks, double* __restrict__ scal) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double t = 0.0;
+  for (int i = 0; i < nchunks; ++i) t = t + chunk_sums[i];
+  scal[0] = t;
+}
+
+__global__ void divide_kernel(double* __restrict__ w, int64_t n, const double* __restrict__ scal) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) w[i] = w[i] / scal[0];  // mc_localization.py:248
+}
+
+// log-domain weights: w = exp(logw - max logw)
+__global__ __launch_bounds__(256) void max_partial_kernel(const double* __restrict__ v, int64_t n,
+                                                          double* __restrict__ part) {
+  __shared__ double sm[4];
+  double m = -INFINITY;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    m = fmax(m, v[i]);
+  for (int d = 32; d >= 1; d >>= 1) m = fmax(m, __shfl_xor(m, d, 64));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+}
+
+__global__ void max_final_kernel(const double* __restrict__ part, int np, double* __restrict__ scal) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double m = -INFINITY;
+  for (int i = 0; i < np; ++i) m = fmax(m, part[i]);
+  scal[1] = m;
+}
+
+__global__ void exp_shift_kernel(const double* __restrict__ logw, double* __restrict__ w, int64_t n,
+                                 const double* __restrict__ scal) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double mx = scal[1];
+  w[i] = (mx == -INFINITY) ? 0.0 : exp(logw[i] - mx);
+}
+
+int launch_normalise(mclhip_ctx* c, int mode) {
+  const int64_t n = c->M;
+  double* w = c->w[c->cur];
+  const unsigned g = (unsigned)((n + 255) / 256);
+  if (mode == MCLHIP_W_LOG) {
+    const int np = 1024;
+    hipLaunchKernelGGL(max_partial_kernel, dim3(np), dim3(256), 0, c->stream, c->logw, n, (double*)c->blk_a);
+    hipLaunchKernelGGL(max_final_kernel, dim3(1), dim3(64), 0, c->stream, (const double*)c->blk_a, np, c->scal);
+    hipLaunchKernelGGL(exp_shift_kernel, dim3(g), dim3(256), 0, c->stream, c->logw, w, n, c->scal);
+  }
+  const int nchunks = (int)((n + kSumChunk - 1) / kSumChunk);
+  hipLaunchKernelGGL(chunk_sum_kernel, dim3(nchunks), dim3(512), 0, c->stream, w, n,
+                     c->chunk_sums);
+  hipLaunchKernelGGL(total_sum_kernel, dim3(1), dim3(64), 0, c->stream, c->chunk_sums, nchunks, c->scal);
+  hipLaunchKernelGGL(divide_kernel, dim3(g), dim3(256), 0, c->stream, w, n, c->scal);
+  MCL_HIP(c, hipGetLastError());
+  return MCLHIP_OK;
+}
+
+// ===========================================================================
+// Device-wide inclusive scans (three kernels: tile reduce, scan of the tile
+// sums by one block, tile scan + offset).  Tiles are 2048 elements.
+// ===========================================================================
+struct KF {  // integer increment and irregular-element flag, scanned together
+  unsigned long long k;
+  unsigned int f;
+};
+__device__ inline KF operator+(const KF& a, const KF& b) { return KF{a.k + b.k, a.f + b.f}; }
+__device__ inline double shfl_up_v(double v, int d) { return __shfl_up(v, d, 64); }
+__device__ inline KF shfl_up_v(const KF& v, int d) {
+  return KF{(unsigned long long)__shfl_up((long long)v.k, d, 64), (unsigned int)__shfl_up((int)v.f, d, 64)};
+}
+__device__ inline double zero_of(double*) { return 0.0; }
+__device__ inline KF zero_of(KF*) { return KF{0ull, 0u}; }
+
+// inclusive scan of one value per thread across a 256-thread block; returns the block total
+template <typename V>
+__device__ inline V block_incl_scan(V v, V* total) {
+  __shared__ V wave_tot[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    V o = shfl_up_v(v, d);
+    if (lane >= d) v = o + v;
+  }
+  if (lane == 63) wave_tot[wv] = v;
+  __syncthreads();
+  V off = zero_of((V*)nullptr);
+  for (int i = 0; i < wv; ++i) off = off + wave_tot[i];
+  V tot = ((wave_tot[0] + wave_tot[1]) + wave_tot[2]) + wave_tot[3];
+  __syncthreads();
+  *total = tot;
+  return off + v;
+}
+
+template <typename V, typename Loader>
+__global__ __launch_bounds__(kScanBlock) void scan_reduce_kernel(Loader ld, int64_t n, V* __restrict__ blk) {
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  V acc = zero_of((V*)nullptr);
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j)
+    if (base + j < n) acc = acc + ld(base + j);
+  V tot;
+  block_incl_scan<V>(acc, &tot);
+  if (threadIdx.x == 0) blk[blockIdx.x] = tot;
+}
+
+// exclusive scan of the tile sums, in place, by a single block
+template <typename V>
+__global__ __launch_bounds__(kScanBlock) void scan_blocks_kernel(V* __restrict__ blk, int nblk) {
+  __shared__ V incl_all[kScanBlock];
+  V carry = zero_of((V*)nullptr);
+  for (int base = 0; base < nblk; base += kScanBlock) {
+    const int i = base + threadIdx.x;
+    V v = (i < nblk) ? blk[i] : zero_of((V*)nullptr);
+    V tot;
+    V inc = block_incl_scan<V>(v, &tot);
+    incl_all[threadIdx.x] = inc;
+    __syncthreads();
+    if (i < nblk) blk[i] = (threadIdx.x == 0) ? carry : carry + incl_all[threadIdx.x - 1];
+    carry = carry + tot;
+    __syncthreads();
+  }
+}
+
+template <typename V, typename Loader, typename Storer>
+__global__ __launch_bounds__(kScanBlock) void scan_apply_kernel(Loader ld, Storer st, int64_t n,
+                                                                const V* __restrict__ blk) {
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  V item[kScanItems];
+  V acc = zero_of((V*)nullptr);
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j) {
+    item[j] = (base + j < n) ? ld(base + j) : zero_of((V*)nullptr);
+    acc = acc + item[j];
+  }
+  V tot;
+  V inc = block_incl_scan<V>(acc, &tot);
+  // exclusive prefix of this thread inside the tile: previous thread's inclusive value
+  __shared__ V incl_all[kScanBlock];
+  incl_all[threadIdx.x] = inc;
+  __syncthreads();
+  V run = blk[blockIdx.x];
+  if (threadIdx.x > 0) run = run + incl_all[threadIdx.x - 1];
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j) {
+    run = run + item[j];
+    if (base + j < n) st(base + j, run, item[j]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Loaders / storers
+// ---------------------------------------------------------------------------
+struct LoadF64 {
+  const double* p;
+  __device__ double operator()(int64_t i) const { return p[i]; }
+};
+struct StoreF64 {
+  double* p;
+  __device__ void operator()(int64_t i, double incl, double) const { p[i] = incl; }
+};
+
+// Order-exact CDF.  The reference's running sum is the strictly sequential
+// chain c_i = fl(c_{i-1} + w_i).  While c stays inside one binade [2^e, 2^(e+1))
+// every step rounds to the same grid u = 2^(e-52), so fl(c + w) = c + u*rint(w/u)
+// whenever w/u is not exactly half-way between two integers: the chain is an
+// exact INTEGER prefix sum there.  An element is "regular" when an approximate
+// scan, with a rigorous error bound, proves that c before and after it lies in
+// one binade, and its w/u is not a tie; all other elements ("irregular": binade
+// crossings, ties, the first element, denormal-range sums) are replayed one by
+// one with true float64 additions, in order, between the integer runs.
+struct ClassifyLoader {
+  const double* ca;  // approximate inclusive scan of wn
+  const double* wn;
+  __device__ KF operator()(int64_t i) const {
+    const double w = wn[i];
+    if (i == 0) return KF{0ull, 1u};
+    if (w == 0.0) return KF{0ull, 0u};  // c unchanged in any binade
+    const double prev = ca[i - 1], cur = ca[i];
+    // |approximate - sequential| <= (i + 64) * 2^-53 * cur; twice that is used
+    const double delta = (double)(i + 64) * 0x1p-52 * cur;
+    const double lo = prev - delta, hi = cur + delta;
+    if (!(lo >= 0x1p-1000) || !(hi < INFINITY)) return KF{0ull, 1u};
+    const int e = ilogb(lo);
+    // below half a grid step of the lower candidate binade the addition leaves c unchanged,
+    // whichever side of a binade boundary c is on (a dominant particle parks c next to 2^0)
+    if (w < ldexp(1.0, e - 53)) return KF{0ull, 0u};
+    if (ilogb(hi) != e) return KF{0ull, 1u};
+    const double s = ldexp(w, 52 - e);  // exact, < 2^53
+    if (s - floor(s) == 0.5) return KF{0ull, 1u};
+    return KF{(unsigned long long)rint(s), 0u};
+  }
+};
+
+struct IrrRecord {
+  int64_t i;
+  double w;
+  unsigned long long P;
+};
+struct RunBase {
+  double c;               // exact running sum right after the irregular element
+  unsigned long long P;   // integer prefix at that element
+  int e;                  // binade of c
+  int pad;
+};
+
+struct StoreKF {
+  unsigned long long* ks;
+  unsigned int* fs;
+  IrrRecord* irr;
+  const double* wn;
+  __device__ void operator()(int64_t i, const KF& incl, const KF& own) const {
+    ks[i] = incl.k;
+    fs[i] = incl.f;
+    if (own.f) irr[incl.f - 1] = IrrRecord{i, wn[i], incl.k};
+  }
+};
+
+// One wavefront walks the irregular elements in order.
+__global__ __launch_bounds__(64) void replay_kernel(const IrrRecord* __restrict__ irr,
+                                                    const unsigned int* __restrict__ fs, int64_t n,
+                                                    RunBase* __restrict__ bases) {
+  const int lane = threadIdx.x;
+  const unsigned int nirr = fs[n - 1];
+  double c = 0.0;
+  unsigned long long Pprev = 0ull;
+  int e_run = -1000;
+  for (unsigned int base = 0; base < nirr; base += 64) {
+    const unsigned int cnt = (nirr - base) < 64u ? (nirr - base) : 64u;
+    IrrRecord rec = IrrRecord{0, 0.0, 0ull};
+    if ((unsigned)lane < cnt) rec = irr[base + lane];
+    RunBase mine = RunBase{0.0, 0ull, -1000, 0};
+    for (unsigned int j = 0; j < cnt; ++j) {
+      const int64_t ii = __shfl((long long)rec.i, (int)j, 64);
+      const double wj = __shfl(rec.w, (int)j, 64);
+      const unsigned long long Pj = (unsigned long long)__shfl((long long)rec.P, (int)j, 64);
+      const double before = c + (double)(Pj - Pprev) * ldexp(1.0, e_run - 52);  // exact
+      c = (ii == 0) ? wj : before + wj;  // the one true float64 addition
+      Pprev = Pj;
+      e_run = (c >= 0x1p-1000 && c < INFINITY) ? ilogb(c) : -1000;
+      if ((unsigned)lane == j) mine = RunBase{c, Pj, e_run, 0};
+    }
+    if ((unsigned)lane < cnt) bases[base + lane] = mine;
+  }
+}
+
+__global__ void finalize_cdf_kernel(const unsigned long long* __restrict__ ks, const unsigned int* __restrict__ fs,
+                                    const RunBase* __restrict__ bases, int64_t n, double* __restrict__ cdf) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const RunBase b = bases[fs[i] - 1];
+  cdf[i] = b.c + (double)(ks[i] - b.P) * ldexp(1.0, b.e - 52);  // exact
+}
+
+// index(m) = number of c_i that are < U_m, U_m = r + m/M  (mc_localization.py:254-257)
+template <typename T>
+__global__ __launch_bounds__(256) void search_gather_kernel(const double* __restrict__ cdf, int64_t n, double r,
+                                                            const T* __restrict__ x, const T* __restrict__ y,
+                                                            const T* __restrict__ th, const double* __restrict__ w,
+                                                            T* __restrict__ x2, T* __restrict__ y2,
+                                                            T* __restrict__ th2, double* __restrict__ w2,
+                                                            int64_t* __restrict__ idx) {
+  int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n) return;
+  const double U = r + ((double)m / (double)n);
+  int64_t lo = 0, hi = n;  // first i with !(U > cdf[i])
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (U > cdf[mid]) lo = mid + 1; else hi = mid;
+  }
+  if (lo > n - 1) lo = n - 1;
+  idx[m] = lo;
+  x2[m] = x[lo];
+  y2[m] = y[lo];
+  th2[m] = th[lo];
+  w2[m] = w[lo];
+}
+
+// The reference's loop by a single lane (verifier, and the path for weight
+// vectors the parallel scan does not accept: NaN / infinite sums).
+__global__ void serial_walk_kernel(const double* __restrict__ wn, int64_t n, double r, int64_t* __restrict__ idx) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double c = wn[0];
+  int64_t i = 0;
+  for (int64_t m = 0; m < n; ++m) {
+    const double U = r + ((double)m / (double)n);
+    while (U > c) {
+      if (i == n - 1) break;
+      i = i + 1;
+      c = c + wn[i];
+    }
+    idx[m] = i;
+  }
+}
+
+template <typename T>
+__global__ void gather_kernel(const int64_t* __restrict__ idx, int64_t n, const T* __restrict__ x,
+                              const T* __restrict__ y, const T* __restrict__ th, const double* __restrict__ w,
+                              T* __restrict__ x2, T* __restrict__ y2, T* __restrict__ th2, double* __restrict__ w2) {
+  int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n) return;
+  const int64_t s = idx[m];
+  x2[m] = x[s];
+  y2[m] = y[s];
+  th2[m] = th[s];
+  w2[m] = w[s];
+}
+
+template <typename T>
+static int resample_typed(mclhip_ctx* c, double r, int algo) {
+  const int64_t n = c->M;
+  const int a = c->cur, b = 1 - c->cur;
+  const double* wn = c->w[a];
+  const unsigned g = (unsigned)((n + 255) / 256);
+  if (algo == MCLHIP_RESAMPLE_SERIAL) {
+    hipLaunchKernelGGL(serial_walk_kernel, dim3(1), dim3(64), 0, c->stream, wn, n, r, c->idx);
+    hipLaunchKernelGGL(gather_kernel<T>, dim3(g), dim3(256), 0, c->stream, c->idx, n, (const T*)c->px[a],
+                       (const T*)c->py[a], (const T*)c->pth[a], wn, (T*)c->px[b], (T*)c->py[b], (T*)c->pth[b],
+                       c->w[b]);
+  } else {
+    const int ntile = (int)((n + kScanTile - 1) / kScanTile);
+    // approximate inclusive scan of the normalised weights
+    LoadF64 lf{wn};
+    StoreF64 sf{c->cdf_approx};
+    hipLaunchKernelGGL((scan_reduce_kernel<double, LoadF64>), dim3(ntile), dim3(kScanBlock), 0, c->stream, lf, n,
+                       (double*)c->blk_a);
+    hipLaunchKernelGGL((scan_blocks_kernel<double>), dim3(1), dim3(kScanBlock), 0, c->stream, (double*)c->blk_a,
+                       ntile);
+    hipLaunchKernelGGL((scan_apply_kernel<double, LoadF64, StoreF64>), dim3(ntile), dim3(kScanBlock), 0, c->stream,
+                       lf, sf, n, (const double*)c->blk_a);
+    // integer increments + irregular flags, scanned together
+    ClassifyLoader cl{c->cdf_approx, wn};
+    StoreKF sk{(unsigned long long*)c->kscan, c->fscan, (IrrRecord*)c->irr, wn};
+    hipLaunchKernelGGL((scan_reduce_kernel<KF, ClassifyLoader>), dim3(ntile), dim3(kScanBlock), 0, c->stream, cl, n,
+                       (KF*)c->blk_b);
+    hipLaunchKernelGGL((scan_blocks_kernel<KF>), dim3(1), dim3(kScanBlock), 0, c->stream, (KF*)c->blk_b, ntile);
+    hipLaunchKernelGGL((scan_apply_kernel<KF, ClassifyLoader, StoreKF>), dim3(ntile), dim3(kScanBlock), 0, c->stream,
+                       cl, sk, n, (const KF*)c->blk_b);
+    hipLaunchKernelGGL(replay_kernel, dim3(1), dim3(64), 0, c->stream, (const IrrRecord*)c->irr, c->fscan, n,
+                       (RunBase*)c->bases);
+    hipLaunchKernelGGL(finalize_cdf_kernel, dim3(g), dim3(256), 0, c->stream, (const unsigned long long*)c->kscan, c->fscan,
+                       (const RunBase*)c->bases, n, c->cdf_exact);
+    hipLaunchKernelGGL(search_gather_kernel<T>, dim3(g), dim3(256), 0, c->stream, c->cdf_exact, n, r,
+                       (const T*)c->px[a], (const T*)c->py[a], (const T*)c->pth[a], wn, (T*)c->px[b], (T*)c->py[b],
+                       (T*)c->pth[b], c->w[b], c->idx);
+  }
+  MCL_HIP(c, hipGetLastError());
+  c->cur = b;
+  return MCLHIP_OK;
+}
+
+int launch_resample(mclhip_ctx* c, double r, int algo) {
+  if (c->dtype == MCLHIP_F32) return resample_typed<float>(c, r, algo);
+  return resample_typed<double>(c, r, algo);
+}
+
+size_t irr_record_bytes() { return sizeof(IrrRecord); }
+size_t run_base_bytes() { return sizeof(RunBase); }
+size_t kf_bytes() { return sizeof(KF); }
+
+}  // namespace mcl

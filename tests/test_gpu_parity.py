@@ -1,0 +1,285 @@
+"""Parity of the HIP path (called through the C ABI) with the oracle and with the
+golden vectors captured from the reference.  Needs an MI355X: `-m gpu`.
+
+Bars: bit-exact for ranges (the float64 min/sqrt chain is exact), hit cells,
+free-cell flags, the normalisation sum and resample indices; 1e-12 relative for
+float64 poses and weights (device sin/cos/exp differ from numpy's by ulps);
+1e-5 relative in float32 state mode.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import mcl_oracle as O
+from util import GOLDEN, load, rel_err, steps
+
+pytestmark = pytest.mark.gpu
+
+ALPHA = [4, 2, 4, 4, 4, 2]
+HALF = 5 * np.pi / 180.0
+
+
+def _lib():
+    from slam_amd import _lib
+    return _lib
+
+
+def _sensor(ctx, angles, sp=None):
+    sp = sp or O.SensorParams()
+    ctx.set_sensor(angles, sp.z_max, sp.sigma_hit, sp.lambda_short, [sp.w_hit, sp.w_short, sp.w_max, sp.w_rand], HALF)
+
+
+def _grid(name, g):
+    return np.load(os.path.join(GOLDEN, "grid_map_g.npy")) if name.startswith("demo") else g["map"]
+
+
+def _ctx(name, g, dtype=None):
+    L = _lib()
+    ctx = L.Context(0, L.F64 if dtype is None else dtype)
+    ctx.set_map(_grid(name, g), O.RES_X, O.RES_Y)
+    _sensor(ctx, list(g["sensor_angles"]))
+    return ctx
+
+
+CASES = ["demo_seed0", "demo_seed1", "demo_seed2", "synth128_b13", "synth256_b180", "synth256_b360"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_sector_query_bit_exact(name):
+    g = load(name)
+    ctx = _ctx(name, g)
+    for s in steps(g):
+        R, Hc = ctx.raycast(s["X_motion"])
+        assert np.array_equal(R, s["ranges"]), "ranges differ in %d places" % np.sum(R != s["ranges"])
+        assert np.array_equal(Hc.astype(np.int64), s["hits"])
+        Rg, Hg = ctx.raycast(s["x_gt_out"])
+        assert np.array_equal(Rg[0], s["z_meas"])
+        assert np.array_equal(Hg[0].astype(np.int64), s["hits_gt"])
+
+
+def test_sector_query_reference_script_answers():
+    """Scenarios of the reference's own test_robot.py: every beam it checks reads < 4 m."""
+    g = load("test_robot")
+    L = _lib()
+    for ci, beam, ok in g["checks"]:
+        ctx = L.Context(0, L.F64)
+        ctx.set_map(g["maps"][ci], O.RES_X, O.RES_Y)
+        _sensor(ctx, list(g["sensor_angles"]))
+        R, _ = ctx.raycast(g["poses"][ci])
+        assert (R[0, beam] < 4) == bool(ok)
+        assert np.allclose(R[0], g["ranges_f32path"][ci], rtol=1e-5, atol=1e-5)
+        ctx.close()
+
+
+def test_sector_query_edges():
+    """Empty map, pose outside the map, NaN pose, headings far outside one turn."""
+    L = _lib()
+    ctx = L.Context(0, L.F64)
+    grid = np.full((40, 56), 255, np.uint8)
+    ctx.set_map(grid, O.RES_X, O.RES_Y)
+    angles = [0, 15, 30, 45, 60, 75, 90, 345, 330, 315, 300, 285, 270]
+    _sensor(ctx, angles)
+    poses = np.array([[1.0, 1.0, 0.3], [-50.0, 3.0, 0.0], [np.nan, 1.0, 0.0], [1.0, 1.0, np.nan], [1e9, 1e9, 1.0]])
+    R, Hc = ctx.raycast(poses)
+    assert np.all(R == 5.0) and np.all(Hc == -1)
+    grid[10, 20] = 0
+    grid[30, 5] = 0
+    grid[0, 0] = 0
+    grid[39, 55] = 0
+    ctx.set_map(grid, O.RES_X, O.RES_Y)
+    lut, cell = O.obstacle_lut(grid)
+    rng = np.random.RandomState(1)
+    poses = np.stack([rng.uniform(-1, 9, 300), rng.uniform(-1, 7, 300), rng.uniform(-15, 15, 300)], 1)
+    R, Hc = ctx.raycast(poses)
+    Ro, Ho = O.sector_query_batch(poses, lut, cell, angles)
+    assert np.array_equal(R, Ro) and np.array_equal(Hc.astype(np.int64), Ho)
+
+
+def test_motion_stage():
+    g = load("motion_only")
+    L = _lib()
+    ctx = L.Context(0, L.F64)
+    ctx.set_map(np.load(os.path.join(GOLDEN, "grid_map_g.npy")), O.RES_X, O.RES_Y)
+    for c, ut in enumerate(g["controls"]):
+        X, pm = ctx.motion(g["X"], ut[0], ut[1], 0.1, g["alpha"], g["noise"][c])
+        assert rel_err(X, g["X_out"][c]) < 1e-12
+        assert np.array_equal(pm, g["pm"][c])
+    Z, pz = ctx.motion(g["X"], 1.5, 0.0, 0.1, g["alpha"], np.zeros((len(g["X"]), 3, 12), np.int16))
+    assert rel_err(Z, g["X_out_zero_noise"]) < 1e-12 and np.array_equal(pz, g["pm_zero_noise"])
+    # noise=False path
+    Xn, _ = ctx.motion(g["X"], 1.5, 0.5, 0.1, g["alpha"], None)
+    Xo, _ = O.motion(g["X"], (1.5, 0.5), 0.1, np.load(os.path.join(GOLDEN, "grid_map_g.npy")), None)
+    assert rel_err(Xn, Xo) < 1e-12
+
+
+def test_compute_px_lattice():
+    g = load("compute_px")
+    L = _lib()
+    ctx = L.Context(0, L.F64)
+    sp = O.SensorParams(z_max=float(g["z_max"]))
+    _sensor(ctx, [0.0], sp)
+    p = ctx.compute_px(g["z"], g["z_true"])
+    assert rel_err(p, g["p"]) < 1e-12
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_sample_normalise_resample_f64(name):
+    g = load(name)
+    ctx = _ctx(name, g)
+    for s in steps(g):
+        ctx.set_particles(s["X_in"])
+        ctx.sample(s["ut"][0], s["ut"][1], float(s["dt"]), ALPHA, s["z_meas"], s["noise"])
+        X, w, logw = ctx.get_particles(True, True, True)
+        assert rel_err(X, s["X_motion"]) < 1e-12
+        ok = (s["w_raw"] > 1e-290) | (s["w_raw"] == 0)
+        assert rel_err(w[ok], s["w_raw"][ok]) < 1e-11
+        assert np.array_equal(w == 0, s["w_raw"] == 0) or np.all(s["w_raw"][w == 0] < 1e-290)
+        pos = s["w_raw"] > 1e-290
+        assert np.allclose(logw[pos], np.log(s["w_raw"][pos]), rtol=1e-12, atol=1e-11)
+        assert np.all(np.isneginf(logw[s["pm"] == 0]))
+        # normalisation: the device sum must equal numpy's sum of the device's own weights, bit for bit
+        total = ctx.normalise(0)
+        assert total == np.sum(w)
+        if not bool(s["resample_ok"]):
+            continue
+        # resampling contract: identical normalised weights + identical r -> identical indices
+        for algo in (0, 1):
+            ctx.set_particles(s["X_motion"], s["w_raw"])
+            assert ctx.normalise(0) == s["w_sum"]
+            idx = ctx.resample(float(s["r"]), algo)
+            assert np.array_equal(idx, s["idx"])
+            X2, w2, _ = ctx.get_particles()
+            assert np.array_equal(X2, s["X_out"]) and np.array_equal(w2, s["w_out"])
+
+
+def test_resample_only_cases_and_large():
+    g = load("resample_only")
+    L = _lib()
+    ctx = L.Context(0, L.F64)
+    for c in range(int(g["n_cases"])):
+        w = g["c%d_w" % c]
+        for algo in (0, 1):
+            ctx.set_particles(np.zeros((len(w), 3)), w)
+            ctx.normalise(0)
+            idx = ctx.resample(float(g["c%d_r" % c]), algo)
+            assert np.array_equal(idx, g["c%d_idx" % c]), (c, algo)
+            assert np.array_equal(ctx.get_particles()[1], g["c%d_w_out" % c])
+    # sizes of the benchmark and weight shapes that stress the order-exact scan
+    rng = np.random.RandomState(5)
+    for M, kind in [(1 << 20, "rand"), (1 << 20, "peaky"), ((1 << 20) + 12345, "zeros"), (300001, "ties"),
+                    (1 << 18, "tiny"), (70000, "equal"), (1 << 20, "copies")]:
+        if kind == "rand":
+            w = rng.rand(M)
+        elif kind == "peaky":
+            w = rng.rand(M) ** 60
+        elif kind == "zeros":
+            w = rng.rand(M) * (rng.rand(M) < 0.2)
+            w[:5000] = 0
+        elif kind == "ties":
+            w = np.ldexp(rng.randint(1, 1 << 20, M).astype(np.float64), -30)  # many exact half-way cases
+        elif kind == "tiny":
+            w = np.exp(-rng.rand(M) * 700)
+        elif kind == "equal":
+            w = np.ones(M)
+        else:
+            w = np.repeat(rng.rand(M // 1024) ** 8, 1024)
+        r = rng.rand() / M
+        ctx.set_particles(np.zeros((M, 3)), w)
+        total = ctx.normalise(0)
+        assert total == np.sum(w)
+        idx = ctx.resample(r, 1)
+        ref = O.resample_indices(w / np.sum(w), r, clamp=True)
+        assert np.array_equal(idx, ref), (M, kind, int(np.sum(idx != ref)))
+    # all-zero weights: NaN after normalisation, every index 0
+    ctx.set_particles(np.zeros((1000, 3)), np.zeros(1000))
+    ctx.normalise(0)
+    for algo in (0, 1):
+        ctx.set_particles(np.zeros((1000, 3)), np.zeros(1000))
+        ctx.normalise(0)
+        assert np.all(ctx.resample(0.0004, algo) == 0)
+
+
+def test_log_weight_mode_matches_product_mode():
+    g = load("synth128_b13")
+    s = steps(g)[0]
+    ctx = _ctx("synth128_b13", g)
+    out = []
+    for mode in (0, 1):
+        ctx.set_particles(s["X_in"])
+        ctx.sample(s["ut"][0], s["ut"][1], float(s["dt"]), ALPHA, s["z_meas"], s["noise"])
+        ctx.normalise(mode)
+        out.append(ctx.get_particles()[1])
+    assert np.allclose(out[0], out[1], rtol=1e-10, atol=1e-300)
+
+
+@pytest.mark.parametrize("name", ["demo_seed0", "synth256_b180"])
+def test_f32_state_mode(name):
+    """float32 particle state: poses and log-weights within 1e-5 relative of the float64
+    reference values; ranges / hit cells are exact for the poses the device holds."""
+    g = load(name)
+    L = _lib()
+    ctx = _ctx(name, g, L.F32)
+    grid = _grid(name, g)
+    lut, cell = O.obstacle_lut(grid)
+    s = steps(g)[0]
+    ctx.set_particles(s["X_in"])
+    ctx.sample(s["ut"][0], s["ut"][1], float(s["dt"]), ALPHA, s["z_meas"], s["noise"])
+    X, w, logw = ctx.get_particles(True, True, True)
+    assert np.max(np.abs(X - s["X_motion"]) / np.maximum(1.0, np.abs(s["X_motion"]))) < 1e-5
+    # stage contract on the device's own float32 poses
+    R, Hc = ctx.raycast(X)
+    Ro, Ho = O.sector_query_batch(X, lut, cell, list(g["sensor_angles"]))
+    assert np.array_equal(R, Ro) and np.array_equal(Hc.astype(np.int64), Ho)
+    wo, lwo, _ = O.weights_from_ranges(Ro, s["z_meas"], O.free_cell(X[:, 0], X[:, 1], grid), O.SensorParams())
+    fin = np.isfinite(lwo)
+    assert np.array_equal(np.isfinite(logw), fin)
+    assert np.max(np.abs(logw[fin] - lwo[fin]) / np.maximum(1.0, np.abs(lwo[fin]))) < 1e-5
+
+
+def test_dropin_class_follows_reference_run():
+    """The drop-in class driven like the reference's __main__ (mc_localization.py:303-331) under
+    the same np.random seed: same initial cloud, same indices, same trajectory."""
+    from slam_amd.mc_localization import MCLocalization, res_x, res_y
+    g = load("demo_seed0")
+    grid = np.load(os.path.join(GOLDEN, "grid_map_g.npy"))
+    np.random.seed(0)
+    x0 = np.array([20 * res_x, 30 * res_y, 0], dtype=np.float32)
+    mcl = MCLocalization(x0, grid)
+    mcl.initialize(x0)
+    for t, s in enumerate(steps(g)):
+        assert np.array_equal(mcl.X, s["X_in"]) if t == 0 else rel_err(mcl.X, s["X_in"]) < 1e-12
+        mcl.sample([1.5, 0], 0.1)
+        assert np.array_equal(np.asarray(mcl.x_gt), s["x_gt_out"])
+        assert np.array_equal(np.asarray(mcl.sensor_ranges), s["z_meas"])
+        mcl.resample()
+        assert np.array_equal(mcl.last_idx, s["idx"])
+        assert rel_err(mcl.X, s["X_out"]) < 1e-12
+        assert rel_err(mcl.w, s["w_out"]) < 1e-11
+    rs = mcl.range_sensor
+    gp = load("compute_px")
+    assert abs(rs.compute_px(1.0, 1.2) - O.beam_px(1.0, 1.2, O.SensorParams())) < 1e-15
+    assert rel_err(rs.compute_px(gp["z"], gp["z_true"]), gp["p"]) < 1e-12
+
+
+def test_device_noise_statistics():
+    """The on-device generator (throughput runs) is not the reference's stream; its draws must have
+    the distribution of Table 5.4: zero mean, standard deviation b/6*sqrt(12*var(U{-1000..1000})/1e6)."""
+    L = _lib()
+    ctx = L.Context(0, L.F64)
+    grid = np.full((64, 64), 255, np.uint8)
+    ctx.set_map(grid, O.RES_X, O.RES_Y)
+    _sensor(ctx, [0.0, 90.0])
+    M = 200000
+    X0 = np.tile(np.array([[4.0, 4.0, 0.0]]), (M, 1))
+    ctx.set_particles(X0)
+    ctx.sample(1.5, 0.0, 0.1, ALPHA, [5.0, 5.0], None, seed=1234)
+    X, _, _ = ctx.get_particles()
+    th = X[:, 2]  # theta' = (w_hat + g_hat) * dt
+    sd_unit = np.sqrt(12 * (2001 ** 2 - 1) / 12.0) * 0.001
+    sd_expected = 0.1 * np.hypot(1.0 * sd_unit, 1.0 * sd_unit)
+    assert abs(np.mean(th)) < 5 * sd_expected / np.sqrt(M)
+    assert abs(np.std(th) / sd_expected - 1) < 0.02
+    ctx.set_particles(X0)
+    ctx.sample(1.5, 0.0, 0.1, ALPHA, [5.0, 5.0], None, seed=1234)
+    assert np.array_equal(ctx.get_particles()[0], X)  # same seed, same draws
