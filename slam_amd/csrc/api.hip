@@ -31,6 +31,7 @@ RayParams make_ray_params(const mclhip_ctx* c) {
   P.r2max = std::pow(c->z_max, 2.0);  // max_sensor_range**2 (mc_localization.py:127)
   P.B = c->B; P.NB = c->NB;
   P.tab_sorted = c->tab_sorted; P.tab_orig = c->tab_orig; P.perm = c->perm; P.lut = c->lut;
+  P.ring = c->ring; P.n_ring = c->n_ring;
   P.ts_min = c->ts_min; P.ts_max = c->ts_max; P.inv_bw = c->inv_bw;
   P.half = c->half;
   P.two_pi_lo = M_PI * 2 - c->half;  // mc_localization.py:149
@@ -42,6 +43,35 @@ RayParams make_ray_params(const mclhip_ctx* c) {
   P.w_hit = c->w4[0]; P.w_short = c->w4[1]; P.w_max = c->w4[2]; P.w_rand = c->w4[3];
   P.p_rand = 1 / c->z_max;                               // range_sensor.py:64
   return P;
+}
+
+// Tile offsets (in 8x8-cell tiles, relative to the tile that holds the particle) that can contain a
+// cell within z_max of some point of that tile, sorted nearest first.
+int build_ring_table(mclhip_ctx* c) {
+  if (!c->ring_dirty) return MCLHIP_OK;
+  if (!c->obst || c->B == 0) return MCLHIP_OK;  // needs both the cell size and z_max
+  const int rcx = (int)std::ceil(c->z_max / c->res_x) + 2, rcy = (int)std::ceil(c->z_max / c->res_y) + 2;
+  const int rtx = (rcx + 7) / 8 + 1, rty = (rcy + 7) / 8 + 1;
+  if (rtx > 127 || rty > 127) return fail(c, MCLHIP_E_LIMIT, "z_max spans more than 127 tiles of 8 cells");
+  const double reach = c->z_max + 2.0 * (c->res_x + c->res_y);
+  std::vector<std::pair<double, uint16_t>> ent;
+  for (int dy = -rty; dy <= rty; ++dy)
+    for (int dx = -rtx; dx <= rtx; ++dx) {
+      const int gx = dx == 0 ? 0 : (std::abs(dx) - 1) * 8 + 1;  // fewest cells between the two tiles
+      const int gy = dy == 0 ? 0 : (std::abs(dy) - 1) * 8 + 1;
+      const double d2 = std::pow(gx * c->res_x, 2.0) + std::pow(gy * c->res_y, 2.0);
+      if (d2 <= reach * reach) ent.push_back({d2, (uint16_t)(((dy + 128) << 8) | (dx + 128))});
+    }
+  std::stable_sort(ent.begin(), ent.end(), [](const std::pair<double, uint16_t>& a, const std::pair<double, uint16_t>& b) { return a.first < b.first; });
+  if (ent.size() > 4096) return fail(c, MCLHIP_E_LIMIT, "z_max / cell size too large for the tile table");
+  std::vector<uint16_t> ring(ent.size());
+  for (size_t i = 0; i < ent.size(); ++i) ring[i] = ent[i].second;
+  if (c->ring) { (void)hipFree(c->ring); c->ring = nullptr; }
+  MCL_HIP(c, hipMalloc((void**)&c->ring, ring.size() * sizeof(uint16_t)));
+  MCL_HIP(c, hipMemcpy(c->ring, ring.data(), ring.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  c->n_ring = (int)ring.size();
+  c->ring_dirty = false;
+  return MCLHIP_OK;
 }
 
 static size_t esize(const mclhip_ctx* c) { return c->dtype == MCLHIP_F32 ? sizeof(float) : sizeof(double); }
@@ -132,6 +162,7 @@ static int need(mclhip_ctx* c, bool map, bool sensor, bool particles) {
   if (map && !c->obst) return fail(c, MCLHIP_E_STATE, "no map: call mclhip_set_map first");
   if (sensor && c->B == 0) return fail(c, MCLHIP_E_STATE, "no sensor: call mclhip_set_sensor first");
   if (particles && c->M == 0) return fail(c, MCLHIP_E_STATE, "no particles: call mclhip_set_particles first");
+  if (map && sensor) return build_ring_table(c);
   return MCLHIP_OK;
 }
 
@@ -207,7 +238,7 @@ void mclhip_destroy(mclhip_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  void* ptrs[] = {c->obst, c->freeb, c->tab_sorted, c->tab_orig, c->perm, c->lut, c->zt, c->etalam, c->zmeas_stage,
+  void* ptrs[] = {c->obst, c->freeb, c->tab_sorted, c->tab_orig, c->perm, c->lut, c->zt, c->etalam, c->zmeas_stage, c->ring,
                   c->px[0], c->px[1], c->py[0], c->py[1], c->pth[0], c->pth[1], c->w[0], c->w[1], c->logw, c->pm,
                   c->sx, c->sy, c->sth, c->sw, c->chunk_sums, c->scal, c->cdf_approx, c->cdf_exact, c->kscan,
                   c->fscan, c->blk_a, c->blk_b, c->irr, c->bases, c->idx, c->noise, c->counters};
@@ -226,6 +257,7 @@ int mclhip_set_map(mclhip_ctx* c, const uint8_t* map, int H, int W, double res_x
   if (!(res_x > 0) || !(res_y > 0)) return fail(c, MCLHIP_E_ARG, "cell size must be positive");
   c->H = H; c->W = W; c->TH = (H + 7) / 8; c->TW = (W + 7) / 8;
   c->res_x = res_x; c->res_y = res_y;
+  c->ring_dirty = true;
   const size_t nt = (size_t)c->TH * c->TW;
   MCL_TRY(dev_alloc(c, &c->obst, nt * sizeof(uint64_t)));
   MCL_TRY(dev_alloc(c, &c->freeb, nt * sizeof(uint64_t)));
@@ -251,6 +283,7 @@ int mclhip_set_sensor(mclhip_ctx* c, const double* angles_deg, int B, double z_m
   for (int k = 0; k < B; ++k)
     if (!std::isfinite(angles_deg[k])) return fail(c, MCLHIP_E_ARG, "beam angles must be finite");
   c->B = B; c->z_max = z_max; c->sigma = sigma_hit; c->lambda = lambda_short; c->half = half;
+  c->ring_dirty = true;
   for (int i = 0; i < 4; ++i) c->w4[i] = w4[i];
   std::vector<double> tab(B), ts(B);
   for (int k = 0; k < B; ++k) tab[k] = angles_deg[k] * M_PI / 180.0;  // angle*np.pi/180.0 (mc_localization.py:143)

@@ -45,18 +45,18 @@ int launch_build_tiles(mclhip_ctx* c, const uint8_t* d_map) {
 // Per-beam constants that depend only on the measured range z*_k:
 //   etalam_k = 1/(1 - exp(-lambda*z*_k)) * lambda      (range_sensor.py:49-50)
 // ---------------------------------------------------------------------------
-__global__ void beam_table_kernel(const double* __restrict__ zmeas, int B, double lambda, double* __restrict__ zt,
-                                  double* __restrict__ etalam) {
-  int k = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void beam_table_kernel(const double* __restrict__ zmeas, const uint16_t* __restrict__ perm, int B,
+                                  double lambda, double* __restrict__ zt, double* __restrict__ etalam) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;  // position in sorted-angle order
   if (k >= B) return;
-  double z = zmeas[k];
+  double z = zmeas[perm[k]];
   double eta = 1.0 / (1.0 - exp(-lambda * z));
   zt[k] = z;
   etalam[k] = eta * lambda;
 }
 
 int launch_beam_table(mclhip_ctx* c) {
-  hipLaunchKernelGGL(beam_table_kernel, dim3((c->B + 63) / 64), dim3(64), 0, c->stream, c->zmeas_stage, c->B,
+  hipLaunchKernelGGL(beam_table_kernel, dim3((c->B + 63) / 64), dim3(64), 0, c->stream, c->zmeas_stage, c->perm, c->B,
                      c->lambda, c->zt, c->etalam);
   MCL_HIP(c, hipGetLastError());
   return MCLHIP_OK;

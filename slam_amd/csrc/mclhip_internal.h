@@ -31,11 +31,13 @@ struct RayParams {
   const double* tab_orig;    // the same, in the caller's beam order
   const uint16_t* perm;      // sorted position -> caller's beam index
   const uint16_t* lut;       // bucket -> first sorted position at or after the bucket's lower edge
+  const uint16_t* ring;      // tile offsets around the particle's tile, nearest first: (dty+128) << 8 | (dtx+128)
+  int n_ring;
   double ts_min, ts_max, inv_bw;
   double half, two_pi_lo, two_pi_hi;
   // beam mixture
-  const double* zt;      // measured range per beam
-  const double* etalam;  // eta_short * lambda_short per beam
+  const double* zt;      // measured range per beam, in sorted-angle order
+  const double* etalam;  // eta_short * lambda_short per beam, in sorted-angle order
   double c_hit;          // 1/sqrt(2*pi*sigma^2)
   double sigma2;         // sigma^2
   double lambda;
@@ -78,6 +80,9 @@ struct mclhip_ctx {
   double* zt = nullptr;      // [B]
   double* etalam = nullptr;  // [B]
   double* zmeas_stage = nullptr;  // [B] staging for z_meas uploads
+  uint16_t* ring = nullptr;       // tile visiting order of the sector query
+  int n_ring = 0;
+  bool ring_dirty = true;         // map resolution or z_max changed since the table was built
 
   // particles (structure of arrays; pose arrays are float or double by dtype)
   int64_t M = 0, cap = 0;
@@ -128,6 +133,7 @@ int fail(mclhip_ctx* c, int code, const std::string& msg);
 // kernels launchers, one per stage; all enqueue on c->stream
 int launch_build_tiles(mclhip_ctx* c, const uint8_t* d_map);
 int launch_beam_table(mclhip_ctx* c);
+int build_ring_table(mclhip_ctx* c);
 int launch_motion(mclhip_ctx* c, void* x, void* y, void* th, uint8_t* pm, int64_t n, const MotionParams& mp,
                   const int16_t* d_noise, int dtype);
 int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, const uint8_t* pm, int64_t n,
