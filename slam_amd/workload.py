@@ -1,7 +1,7 @@
 """Synthetic inputs of the benchmark configurations (maps, beam sets, particle clouds).
 
 Everything is generated from fixed numpy RandomState seeds so that the GPU path,
-the oracle and every rank of a multi-GPU run see identical inputs.
+the CPU checker and every rank of a multi-GPU run see identical inputs.
 """
 import numpy as np
 
