@@ -150,6 +150,60 @@ int mclhip_sync(mclhip_ctx* ctx);
 int mclhip_snapshot_particles(mclhip_ctx* ctx);
 int mclhip_restore_particles_async(mclhip_ctx* ctx);
 
+/* One filter over several GPUs ---------------------------------------------
+ * One process and one context per GPU; rank g owns the contiguous global
+ * particle range [first_index, first_index + M_local).  The reference is a
+ * single-process loop, so these calls have no counterpart there: they are the
+ * per-rank halves of mc_localization.py:248 (the sum) and :250-262 (the walk);
+ * the host combines the small per-rank results (sums, record lists, counts)
+ * across ranks and moves the packed rows.  Pointers named `rows` may be host
+ * or device memory (the library copies with hipMemcpyDefault). */
+
+/* Declares which slice of the global particle vector this context holds. */
+int mclhip_shard_set(mclhip_ctx* ctx, int64_t first_index, int64_t m_total);
+
+/* mclhip_sample for the local slice; the device generator is keyed by the
+ * GLOBAL particle index, so the draws do not depend on the sharding.
+ * weight_mode MCLHIP_W_LOG skips the raw product. */
+int mclhip_shard_sample(mclhip_ctx* ctx, double v, double omega, double dt, const double alpha[6],
+                        const int16_t* noise_ints, uint64_t seed, const double* z_meas, int weight_mode);
+
+/* Largest log-weight of the local slice (MCLHIP_W_LOG only). */
+int mclhip_shard_max_logw(mclhip_ctx* ctx, double* max_out);
+
+/* Forms the local raw weights (MCLHIP_W_LOG: exp(logw - gmax)) and returns the
+ * sums of the local 8192-element chunks, each in numpy's pairwise order.
+ * M_local must be a multiple of 8192 on every rank but the last, so that the
+ * chunks are those of the global vector. */
+int mclhip_shard_weights(mclhip_ctx* ctx, int mode, double gmax, double* chunk_sums_out, int64_t n_chunks);
+
+/* Divides by the global sum and runs the local half of the order-exact scan.
+ * approx_offset: approximate sum of the normalised weights of all lower ranks.
+ * Returns the local integer total and the number of local irregular records. */
+int mclhip_shard_scan(mclhip_ctx* ctx, double total, double approx_offset, uint64_t* k_total, uint32_t* n_records);
+
+/* Copies the local irregular records out: n_records x {int64 global index,
+ * double weight, uint64 local integer prefix} (24 bytes each). */
+int mclhip_shard_get_records(mclhip_ctx* ctx, void* records_out, int64_t cap_records);
+
+/* Takes the records of ALL ranks in rank order, integer prefixes already made
+ * global by the caller, replays them and finishes the local running sums.
+ * P_off / F_off: integer total / record count of all lower ranks. */
+int mclhip_shard_finalize(mclhip_ctx* ctx, const void* all_records, int64_t n_all, uint64_t P_off, uint32_t F_off);
+
+/* counts_out[j] = number of local running sums that are < U[j]. */
+int mclhip_shard_count_below(mclhip_ctx* ctx, const double* U, int n, int64_t* counts_out);
+
+/* Packs the local particles [lo[s], hi[s]) of every slice s, one after the
+ * other, as rows of five doubles (x, y, theta, w, running sum) into `rows`. */
+int mclhip_shard_pack(mclhip_ctx* ctx, const int64_t* lo, const int64_t* hi, int nslices, void* rows);
+
+/* Resamples the local positions from L received rows (global source indices
+ * row0_global ...): index = number of received running sums < r + m/M_total,
+ * clamped to the last row; gathers pose and weight.  idx_out nullable. */
+int mclhip_shard_unpack_resample(mclhip_ctx* ctx, const void* rows, int64_t L, double r, int64_t row0_global,
+                                 int64_t* idx_out);
+
 /* Measurement ------------------------------------------------------------ */
 
 /* Per-kernel timing with HIP events on the context's own stream.

@@ -51,6 +51,17 @@ PROTOTYPES = {
     "mclhip_sync": (C.c_int, [_ctx_p]),
     "mclhip_snapshot_particles": (C.c_int, [_ctx_p]),
     "mclhip_restore_particles_async": (C.c_int, [_ctx_p]),
+    "mclhip_shard_set": (C.c_int, [_ctx_p, C.c_int64, C.c_int64]),
+    "mclhip_shard_sample": (C.c_int, [_ctx_p, C.c_double, C.c_double, C.c_double, _dbl_p, _i16_p, C.c_uint64, _dbl_p,
+                                      C.c_int]),
+    "mclhip_shard_max_logw": (C.c_int, [_ctx_p, _dbl_p]),
+    "mclhip_shard_weights": (C.c_int, [_ctx_p, C.c_int, C.c_double, _dbl_p, C.c_int64]),
+    "mclhip_shard_scan": (C.c_int, [_ctx_p, C.c_double, C.c_double, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    "mclhip_shard_get_records": (C.c_int, [_ctx_p, C.c_void_p, C.c_int64]),
+    "mclhip_shard_finalize": (C.c_int, [_ctx_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_uint32]),
+    "mclhip_shard_count_below": (C.c_int, [_ctx_p, _dbl_p, C.c_int, _i64_p]),
+    "mclhip_shard_pack": (C.c_int, [_ctx_p, _i64_p, _i64_p, C.c_int, C.c_void_p]),
+    "mclhip_shard_unpack_resample": (C.c_int, [_ctx_p, C.c_void_p, C.c_int64, C.c_double, C.c_int64, _i64_p]),
     "mclhip_timing_enable": (C.c_int, [_ctx_p, C.c_int]),
     "mclhip_timing_get": (C.c_int, [_ctx_p, C.c_int, _i64_p, _dbl_p]),
 }
@@ -233,6 +244,70 @@ class Context:
 
     def restore_particles_async(self):
         self._ck(self.lib.mclhip_restore_particles_async(self.h), "mclhip_restore_particles_async")
+
+    # one filter over several GPUs (per-rank halves; see slam_amd/sharded.py) -------------
+    RECORD_DTYPE = np.dtype([("i", "<i8"), ("w", "<f8"), ("P", "<u8")])
+
+    def shard_set(self, first_index, m_total):
+        self._ck(self.lib.mclhip_shard_set(self.h, int(first_index), int(m_total)), "mclhip_shard_set")
+
+    def shard_sample(self, v, omega, dt, alpha, z_meas, noise_ints, seed, weight_mode):
+        al = _f64(alpha, (6,))
+        zm = _f64(z_meas, (self.B,))
+        nz = self._noise(noise_ints)
+        self._ck(self.lib.mclhip_shard_sample(self.h, float(v), float(omega), float(dt), _p(al, _dbl_p),
+                                              _p(nz, _i16_p), int(seed), _p(zm, _dbl_p), int(weight_mode)),
+                 "mclhip_shard_sample")
+
+    def shard_max_logw(self):
+        m = C.c_double(0.0)
+        self._ck(self.lib.mclhip_shard_max_logw(self.h, C.byref(m)), "mclhip_shard_max_logw")
+        return m.value
+
+    def shard_weights(self, mode, gmax):
+        n = (self.num_particles() + 8191) // 8192
+        out = np.empty(n)
+        self._ck(self.lib.mclhip_shard_weights(self.h, int(mode), float(gmax), _p(out, _dbl_p), n),
+                 "mclhip_shard_weights")
+        return out
+
+    def shard_scan(self, total, approx_offset):
+        k = C.c_uint64(0)
+        n = C.c_uint32(0)
+        self._ck(self.lib.mclhip_shard_scan(self.h, float(total), float(approx_offset), C.byref(k), C.byref(n)),
+                 "mclhip_shard_scan")
+        return int(k.value), int(n.value)
+
+    def shard_get_records(self, n):
+        out = np.zeros(n, self.RECORD_DTYPE)
+        self._ck(self.lib.mclhip_shard_get_records(self.h, out.ctypes.data_as(C.c_void_p), n),
+                 "mclhip_shard_get_records")
+        return out
+
+    def shard_finalize(self, all_records, p_off, f_off):
+        rec = np.ascontiguousarray(all_records, dtype=self.RECORD_DTYPE)
+        self._ck(self.lib.mclhip_shard_finalize(self.h, rec.ctypes.data_as(C.c_void_p), len(rec),
+                                                int(p_off) & 0xFFFFFFFFFFFFFFFF, int(f_off)), "mclhip_shard_finalize")
+
+    def shard_count_below(self, U):
+        U = _f64(U)
+        out = np.empty(len(U), np.int64)
+        self._ck(self.lib.mclhip_shard_count_below(self.h, _p(U, _dbl_p), len(U), _p(out, _i64_p)),
+                 "mclhip_shard_count_below")
+        return out
+
+    def shard_pack(self, lo, hi, rows_ptr):
+        lo = np.ascontiguousarray(lo, dtype=np.int64)
+        hi = np.ascontiguousarray(hi, dtype=np.int64)
+        self._ck(self.lib.mclhip_shard_pack(self.h, _p(lo, _i64_p), _p(hi, _i64_p), len(lo), C.c_void_p(rows_ptr)),
+                 "mclhip_shard_pack")
+
+    def shard_unpack_resample(self, rows_ptr, L, r, row0_global, want_idx=False):
+        idx = np.empty(self.num_particles(), np.int64) if want_idx else None
+        self._ck(self.lib.mclhip_shard_unpack_resample(self.h, C.c_void_p(rows_ptr), int(L), float(r),
+                                                       int(row0_global), _p(idx, _i64_p)),
+                 "mclhip_shard_unpack_resample")
+        return idx
 
     def timing_enable(self, on=True):
         self._ck(self.lib.mclhip_timing_enable(self.h, 1 if on else 0), "mclhip_timing_enable")

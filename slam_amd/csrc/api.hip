@@ -155,6 +155,7 @@ static MotionParams make_motion_params(const mclhip_ctx* c, double v, double ome
   mp.TW = c->TW; mp.TH = c->TH; mp.W = c->W; mp.H = c->H;
   mp.noise_mode = noise_mode;
   mp.seed = seed;
+  mp.index0 = c->first_index;
   return mp;
 }
 
@@ -241,7 +242,8 @@ void mclhip_destroy(mclhip_ctx* c) {
   void* ptrs[] = {c->obst, c->freeb, c->tab_sorted, c->tab_orig, c->perm, c->lut, c->zt, c->etalam, c->zmeas_stage, c->ring,
                   c->px[0], c->px[1], c->py[0], c->py[1], c->pth[0], c->pth[1], c->w[0], c->w[1], c->logw, c->pm,
                   c->sx, c->sy, c->sth, c->sw, c->chunk_sums, c->scal, c->cdf_approx, c->cdf_exact, c->kscan,
-                  c->fscan, c->blk_a, c->blk_b, c->irr, c->bases, c->idx, c->noise, c->counters};
+                  c->fscan, c->blk_a, c->blk_b, c->irr, c->bases, c->idx, c->noise, c->counters, c->g_records, c->g_bases,
+                  c->rows_send, c->rows_recv, c->small_d, c->small_i};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -573,6 +575,160 @@ int mclhip_restore_particles_async(mclhip_ctx* c) {
   MCL_HIP(c, hipMemcpyAsync(c->py[a], c->sy, M * es, hipMemcpyDeviceToDevice, c->stream));
   MCL_HIP(c, hipMemcpyAsync(c->pth[a], c->sth, M * es, hipMemcpyDeviceToDevice, c->stream));
   MCL_HIP(c, hipMemcpyAsync(c->w[a], c->sw, M * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  return MCLHIP_OK;
+}
+
+// ---- one filter over several GPUs ----------------------------------------------------------
+int mclhip_shard_set(mclhip_ctx* c, int64_t first_index, int64_t m_total) {
+  if (!c) return MCLHIP_E_ARG;
+  if (first_index < 0 || m_total <= 0 || first_index >= m_total) return fail(c, MCLHIP_E_ARG, "bad shard range");
+  c->first_index = first_index;
+  c->m_total = m_total;
+  return MCLHIP_OK;
+}
+
+int mclhip_shard_sample(mclhip_ctx* c, double v, double omega, double dt, const double alpha[6],
+                        const int16_t* noise_ints, uint64_t seed, const double* z_meas, int weight_mode) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, true, true, true));
+  if (!alpha) return fail(c, MCLHIP_E_ARG, "alpha is NULL");
+  MCL_TRY(upload_zmeas(c, z_meas));
+  if (noise_ints) MCL_TRY(upload_noise(c, noise_ints));
+  MCL_TRY(enqueue_sample(c, v, omega, dt, alpha, noise_ints ? 1 : 2, seed, c->spans, weight_mode == MCLHIP_W_PRODUCT));
+  MCL_HIP(c, hipStreamSynchronize(c->stream));
+  span_collect(c, c->spans);
+  return MCLHIP_OK;
+}
+
+int mclhip_shard_max_logw(mclhip_ctx* c, double* max_out) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, false, false, true));
+  if (!max_out) return fail(c, MCLHIP_E_ARG, "max_out is NULL");
+  span_begin(c, c->spans, 2);
+  MCL_TRY(launch_shard_max_logw(c));
+  span_end(c, c->spans);
+  MCL_HIP(c, hipMemcpyAsync(max_out, c->scal + 1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  MCL_HIP(c, hipStreamSynchronize(c->stream));
+  span_collect(c, c->spans);
+  return MCLHIP_OK;
+}
+
+int mclhip_shard_weights(mclhip_ctx* c, int mode, double gmax, double* chunk_sums_out, int64_t n_chunks) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, false, false, true));
+  const int64_t nch = (c->M + kSumChunk - 1) / kSumChunk;
+  if (!chunk_sums_out || n_chunks != nch) return fail(c, MCLHIP_E_ARG, "chunk_sums_out NULL or wrong chunk count");
+  span_begin(c, c->spans, 2);
+  MCL_TRY(launch_shard_weights(c, mode, gmax));
+  span_end(c, c->spans);
+  MCL_HIP(c, hipMemcpyAsync(chunk_sums_out, c->chunk_sums, nch * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  MCL_HIP(c, hipStreamSynchronize(c->stream));
+  span_collect(c, c->spans);
+  return MCLHIP_OK;
+}
+
+int mclhip_shard_scan(mclhip_ctx* c, double total, double approx_offset, uint64_t* k_total, uint32_t* n_records) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, false, false, true));
+  if (!k_total || !n_records) return fail(c, MCLHIP_E_ARG, "output pointer is NULL");
+  if (c->m_total <= 0) return fail(c, MCLHIP_E_STATE, "call mclhip_shard_set first");
+  span_begin(c, c->spans, 2);
+  MCL_TRY(launch_shard_scan(c, total, approx_offset, c->first_index));
+  span_end(c, c->spans);
+  MCL_HIP(c, hipMemcpyAsync(k_total, c->kscan + (c->M - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+  MCL_HIP(c, hipMemcpyAsync(n_records, c->fscan + (c->M - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  MCL_HIP(c, hipStreamSynchronize(c->stream));
+  span_collect(c, c->spans);
+  return MCLHIP_OK;
+}
+
+int mclhip_shard_get_records(mclhip_ctx* c, void* records_out, int64_t cap_records) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, false, false, true));
+  uint32_t nrec = 0;
+  MCL_HIP(c, hipMemcpy(&nrec, c->fscan + (c->M - 1), sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (cap_records < (int64_t)nrec || (!records_out && nrec)) return fail(c, MCLHIP_E_ARG, "records_out too small");
+  if (nrec) MCL_HIP(c, hipMemcpy(records_out, c->irr, (size_t)nrec * irr_record_bytes(), hipMemcpyDeviceToHost));
+  return MCLHIP_OK;
+}
+
+int mclhip_shard_finalize(mclhip_ctx* c, const void* all_records, int64_t n_all, uint64_t P_off, uint32_t F_off) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, false, false, true));
+  if (!all_records || n_all <= 0) return fail(c, MCLHIP_E_ARG, "the global record list is empty (element 0 is always a record)");
+  if (n_all > c->g_records_cap) {
+    const int64_t cap = n_all + n_all / 2 + 1024;
+    MCL_TRY(dev_alloc(c, &c->g_records, (size_t)cap * irr_record_bytes()));
+    MCL_TRY(dev_alloc(c, &c->g_bases, (size_t)cap * run_base_bytes()));
+    c->g_records_cap = cap;
+  }
+  MCL_HIP(c, hipMemcpyAsync(c->g_records, all_records, (size_t)n_all * irr_record_bytes(), hipMemcpyHostToDevice, c->stream));
+  span_begin(c, c->spans, 2);
+  MCL_TRY(launch_shard_finalize(c, c->g_records, n_all, c->g_bases, P_off, F_off));
+  span_end(c, c->spans);
+  MCL_HIP(c, hipStreamSynchronize(c->stream));
+  span_collect(c, c->spans);
+  return MCLHIP_OK;
+}
+
+int mclhip_shard_count_below(mclhip_ctx* c, const double* U, int n, int64_t* counts_out) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, false, false, true));
+  if (!U || !counts_out || n <= 0 || n > 1024) return fail(c, MCLHIP_E_ARG, "U/counts NULL or n outside 1..1024");
+  if (!c->small_d) MCL_TRY(dev_alloc(c, &c->small_d, 1024 * sizeof(double)));
+  if (!c->small_i) MCL_TRY(dev_alloc(c, &c->small_i, 1024 * sizeof(int64_t)));
+  MCL_HIP(c, hipMemcpyAsync(c->small_d, U, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  MCL_TRY(launch_count_below(c, c->small_d, n, c->small_i));
+  MCL_HIP(c, hipMemcpyAsync(counts_out, c->small_i, n * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+  MCL_HIP(c, hipStreamSynchronize(c->stream));
+  return MCLHIP_OK;
+}
+
+int mclhip_shard_pack(mclhip_ctx* c, const int64_t* lo, const int64_t* hi, int nslices, void* rows) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, false, false, true));
+  if (!lo || !hi || nslices <= 0) return fail(c, MCLHIP_E_ARG, "lo/hi NULL or no slices");
+  int64_t total = 0;
+  for (int s = 0; s < nslices; ++s) {
+    if (lo[s] < 0 || hi[s] > c->M || hi[s] < lo[s]) return fail(c, MCLHIP_E_ARG, "slice outside the local range");
+    total += hi[s] - lo[s];
+  }
+  if (total == 0) return MCLHIP_OK;
+  if (!rows) return fail(c, MCLHIP_E_ARG, "rows is NULL");
+  if (total > c->rows_send_cap) {
+    MCL_TRY(dev_alloc(c, &c->rows_send, (size_t)(total + total / 4) * 5 * sizeof(double)));
+    c->rows_send_cap = total + total / 4;
+  }
+  span_begin(c, c->spans, 2);
+  int64_t off = 0;
+  for (int s = 0; s < nslices; ++s) {
+    MCL_TRY(launch_pack_rows(c, lo[s], hi[s], (double*)c->rows_send + off * 5));
+    off += hi[s] - lo[s];
+  }
+  span_end(c, c->spans);
+  MCL_HIP(c, hipMemcpyAsync(rows, c->rows_send, (size_t)total * 5 * sizeof(double), hipMemcpyDefault, c->stream));
+  MCL_HIP(c, hipStreamSynchronize(c->stream));
+  span_collect(c, c->spans);
+  return MCLHIP_OK;
+}
+
+int mclhip_shard_unpack_resample(mclhip_ctx* c, const void* rows, int64_t L, double r, int64_t row0_global,
+                                 int64_t* idx_out) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, false, false, true));
+  if (!rows || L <= 0) return fail(c, MCLHIP_E_ARG, "rows NULL or empty");
+  if (c->m_total <= 0) return fail(c, MCLHIP_E_STATE, "call mclhip_shard_set first");
+  if (L > c->rows_recv_cap) {
+    MCL_TRY(dev_alloc(c, &c->rows_recv, (size_t)(L + L / 4) * 5 * sizeof(double)));
+    c->rows_recv_cap = L + L / 4;
+  }
+  MCL_HIP(c, hipMemcpyAsync(c->rows_recv, rows, (size_t)L * 5 * sizeof(double), hipMemcpyDefault, c->stream));
+  span_begin(c, c->spans, 2);
+  MCL_TRY(launch_unpack_resample(c, (const double*)c->rows_recv, L, c->first_index, c->m_total, r, row0_global));
+  span_end(c, c->spans);
+  MCL_HIP(c, hipStreamSynchronize(c->stream));
+  span_collect(c, c->spans);
+  if (idx_out) MCL_HIP(c, hipMemcpy(idx_out, c->idx, c->M * sizeof(int64_t), hipMemcpyDeviceToHost));
   return MCLHIP_OK;
 }
 

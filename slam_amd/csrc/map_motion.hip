@@ -132,7 +132,8 @@ __global__ __launch_bounds__(256) void motion_kernel(T* __restrict__ xs, T* __re
     } else {
 #pragma unroll
       for (int b = 0; b < 9; ++b) {
-        uint32_t ctr[4] = {(uint32_t)i, (uint32_t)((uint64_t)i >> 32), (uint32_t)b, 0x4d434cu};
+        const uint64_t gi = (uint64_t)(mp.index0 + i);
+        uint32_t ctr[4] = {(uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)b, 0x4d434cu};
         philox4x32(ctr, (uint32_t)mp.seed, (uint32_t)(mp.seed >> 32));
 #pragma unroll
         for (int j = 0; j < 4; ++j) k[b * 4 + j] = (int)(((uint64_t)ctr[j] * 2001ull) >> 32) - 1000;

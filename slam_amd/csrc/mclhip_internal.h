@@ -53,6 +53,7 @@ struct MotionParams {
   int TW, TH, W, H;
   int noise_mode;        // 0 none, 1 pre-drawn integers, 2 device generator
   uint64_t seed;
+  int64_t index0;        // global index of particle 0 (keys the device generator)
 };
 
 }  // namespace mcl
@@ -111,6 +112,14 @@ struct mclhip_ctx {
   int16_t* noise = nullptr;      // [M][3][12] staging for pre-drawn integers
   uint32_t* counters = nullptr;  // small device counters
 
+  // multi-GPU: this context's slice of one global particle vector
+  int64_t first_index = 0, m_total = 0;
+  void* g_records = nullptr; int64_t g_records_cap = 0;   // global irregular-record list
+  void* g_bases = nullptr;
+  void* rows_send = nullptr; int64_t rows_send_cap = 0;   // packed rows handed to / received from the exchange
+  void* rows_recv = nullptr; int64_t rows_recv_cap = 0;
+  double* small_d = nullptr; int64_t* small_i = nullptr;  // [1024] staging for boundary queries
+
   // timing
   bool timing = false;
   int64_t t_launch[3] = {0, 0, 0};
@@ -141,6 +150,15 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
 int launch_compute_px(mclhip_ctx* c, const double* z, const double* zt, int64_t n, double* p);
 int launch_normalise(mclhip_ctx* c, int mode);
 int launch_resample(mclhip_ctx* c, double r, int algo);
+int launch_shard_max_logw(mclhip_ctx* c);
+int launch_shard_weights(mclhip_ctx* c, int mode, double gmax);
+int launch_shard_scan(mclhip_ctx* c, double total, double approx_offset, int64_t first_index);
+int launch_shard_finalize(mclhip_ctx* c, const void* d_records, int64_t nrec, void* d_bases, uint64_t P_off,
+                          uint32_t F_off);
+int launch_count_below(mclhip_ctx* c, const double* d_U, int nu, int64_t* d_counts);
+int launch_pack_rows(mclhip_ctx* c, int64_t lo, int64_t hi, double* d_dst);
+int launch_unpack_resample(mclhip_ctx* c, const double* d_rows, int64_t L, int64_t first_index, int64_t m_total,
+                           double r, int64_t row0_global);
 RayParams make_ray_params(const mclhip_ctx* c);
 
 }  // namespace mcl

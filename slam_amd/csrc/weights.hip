@@ -243,13 +243,16 @@ struct StoreF64 {
 // crossings, ties, the first element, denormal-range sums) are replayed one by
 // one with true float64 additions, in order, between the integer runs.
 struct ClassifyLoader {
-  const double* ca;  // approximate inclusive scan of wn
+  const double* ca;  // approximate inclusive scan of the local wn
   const double* wn;
-  __device__ KF operator()(int64_t i) const {
-    const double w = wn[i];
+  int64_t i0;        // global index of local element 0 (0 on a single GPU)
+  double off;        // approximate running sum of everything before local element 0
+  __device__ KF operator()(int64_t il) const {
+    const double w = wn[il];
+    const int64_t i = i0 + il;
     if (i == 0) return KF{0ull, 1u};
     if (w == 0.0) return KF{0ull, 0u};  // c unchanged in any binade
-    const double prev = ca[i - 1], cur = ca[i];
+    const double prev = (il == 0) ? off : ca[il - 1] + off, cur = ca[il] + off;
     // |approximate - sequential| <= (i + 64) * 2^-53 * cur; twice that is used
     const double delta = (double)(i + 64) * 0x1p-52 * cur;
     const double lo = prev - delta, hi = cur + delta;
@@ -282,19 +285,20 @@ struct StoreKF {
   unsigned int* fs;
   IrrRecord* irr;
   const double* wn;
+  int64_t i0;
   __device__ void operator()(int64_t i, const KF& incl, const KF& own) const {
     ks[i] = incl.k;
     fs[i] = incl.f;
-    if (own.f) irr[incl.f - 1] = IrrRecord{i, wn[i], incl.k};
+    if (own.f) irr[incl.f - 1] = IrrRecord{i0 + i, wn[i], incl.k};
   }
 };
 
 // One wavefront walks the irregular elements in order.
 __global__ __launch_bounds__(64) void replay_kernel(const IrrRecord* __restrict__ irr,
                                                     const unsigned int* __restrict__ fs, int64_t n,
-                                                    RunBase* __restrict__ bases) {
+                                                    int64_t nirr_given, RunBase* __restrict__ bases) {
   const int lane = threadIdx.x;
-  const unsigned int nirr = fs[n - 1];
+  const unsigned int nirr = fs ? fs[n - 1] : (unsigned int)nirr_given;
   double c = 0.0;
   unsigned long long Pprev = 0ull;
   int e_run = -1000;
@@ -318,11 +322,12 @@ __global__ __launch_bounds__(64) void replay_kernel(const IrrRecord* __restrict_
 }
 
 __global__ void finalize_cdf_kernel(const unsigned long long* __restrict__ ks, const unsigned int* __restrict__ fs,
-                                    const RunBase* __restrict__ bases, int64_t n, double* __restrict__ cdf) {
+                                    const RunBase* __restrict__ bases, int64_t n, unsigned long long P_off,
+                                    unsigned int F_off, double* __restrict__ cdf) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const RunBase b = bases[fs[i] - 1];
-  cdf[i] = b.c + (double)(ks[i] - b.P) * ldexp(1.0, b.e - 52);  // exact
+  const RunBase b = bases[F_off + fs[i] - 1];
+  cdf[i] = b.c + (double)(P_off + ks[i] - b.P) * ldexp(1.0, b.e - 52);  // exact
 }
 
 // index(m) = number of c_i that are < U_m, U_m = r + m/M  (mc_localization.py:254-257)
@@ -402,17 +407,17 @@ static int resample_typed(mclhip_ctx* c, double r, int algo) {
     hipLaunchKernelGGL((scan_apply_kernel<double, LoadF64, StoreF64>), dim3(ntile), dim3(kScanBlock), 0, c->stream,
                        lf, sf, n, (const double*)c->blk_a);
     // integer increments + irregular flags, scanned together
-    ClassifyLoader cl{c->cdf_approx, wn};
-    StoreKF sk{(unsigned long long*)c->kscan, c->fscan, (IrrRecord*)c->irr, wn};
+    ClassifyLoader cl{c->cdf_approx, wn, 0, 0.0};
+    StoreKF sk{(unsigned long long*)c->kscan, c->fscan, (IrrRecord*)c->irr, wn, 0};
     hipLaunchKernelGGL((scan_reduce_kernel<KF, ClassifyLoader>), dim3(ntile), dim3(kScanBlock), 0, c->stream, cl, n,
                        (KF*)c->blk_b);
     hipLaunchKernelGGL((scan_blocks_kernel<KF>), dim3(1), dim3(kScanBlock), 0, c->stream, (KF*)c->blk_b, ntile);
     hipLaunchKernelGGL((scan_apply_kernel<KF, ClassifyLoader, StoreKF>), dim3(ntile), dim3(kScanBlock), 0, c->stream,
                        cl, sk, n, (const KF*)c->blk_b);
     hipLaunchKernelGGL(replay_kernel, dim3(1), dim3(64), 0, c->stream, (const IrrRecord*)c->irr, c->fscan, n,
-                       (RunBase*)c->bases);
-    hipLaunchKernelGGL(finalize_cdf_kernel, dim3(g), dim3(256), 0, c->stream, (const unsigned long long*)c->kscan, c->fscan,
-                       (const RunBase*)c->bases, n, c->cdf_exact);
+                       (int64_t)0, (RunBase*)c->bases);
+    hipLaunchKernelGGL(finalize_cdf_kernel, dim3(g), dim3(256), 0, c->stream, (const unsigned long long*)c->kscan,
+                       c->fscan, (const RunBase*)c->bases, n, 0ull, 0u, c->cdf_exact);
     hipLaunchKernelGGL(search_gather_kernel<T>, dim3(g), dim3(256), 0, c->stream, c->cdf_exact, n, r,
                        (const T*)c->px[a], (const T*)c->py[a], (const T*)c->pth[a], wn, (T*)c->px[b], (T*)c->py[b],
                        (T*)c->pth[b], c->w[b], c->idx);
@@ -425,6 +430,179 @@ static int resample_typed(mclhip_ctx* c, double r, int algo) {
 int launch_resample(mclhip_ctx* c, double r, int algo) {
   if (c->dtype == MCLHIP_F32) return resample_typed<float>(c, r, algo);
   return resample_typed<double>(c, r, algo);
+}
+
+
+// ===========================================================================
+// One filter over several GPUs.  Every rank owns a contiguous range of the
+// global particle vector; the pieces below are the per-rank halves of the
+// normalisation and of the order-exact resampling, the host combines them.
+// ===========================================================================
+__global__ void divide_by_kernel(double* __restrict__ w, int64_t n, double total) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) w[i] = w[i] / total;  // mc_localization.py:248 with the global sum
+}
+
+__global__ void exp_shift_by_kernel(const double* __restrict__ logw, double* __restrict__ w, int64_t n, double mx) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  w[i] = (mx == -INFINITY) ? 0.0 : exp(logw[i] - mx);
+}
+
+int launch_shard_max_logw(mclhip_ctx* c) {
+  const int np = 1024;
+  hipLaunchKernelGGL(max_partial_kernel, dim3(np), dim3(256), 0, c->stream, c->logw, c->M, (double*)c->blk_a);
+  hipLaunchKernelGGL(max_final_kernel, dim3(1), dim3(64), 0, c->stream, (const double*)c->blk_a, np, c->scal);
+  MCL_HIP(c, hipGetLastError());
+  return MCLHIP_OK;
+}
+
+// form the raw weights (log mode: exp(logw - gmax)) and this rank's 8192-element chunk sums
+int launch_shard_weights(mclhip_ctx* c, int mode, double gmax) {
+  const int64_t n = c->M;
+  double* w = c->w[c->cur];
+  const unsigned g = (unsigned)((n + 255) / 256);
+  if (mode == MCLHIP_W_LOG)
+    hipLaunchKernelGGL(exp_shift_by_kernel, dim3(g), dim3(256), 0, c->stream, c->logw, w, n, gmax);
+  const int nchunks = (int)((n + kSumChunk - 1) / kSumChunk);
+  hipLaunchKernelGGL(chunk_sum_kernel, dim3(nchunks), dim3(512), 0, c->stream, w, n, c->chunk_sums);
+  MCL_HIP(c, hipGetLastError());
+  return MCLHIP_OK;
+}
+
+// divide by the global sum, approximate scan, classification, integer scan; leaves this rank's
+// irregular records (global index, weight, LOCAL integer prefix) in c->irr
+int launch_shard_scan(mclhip_ctx* c, double total, double approx_offset, int64_t first_index) {
+  const int64_t n = c->M;
+  double* wn = c->w[c->cur];
+  const unsigned g = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(divide_by_kernel, dim3(g), dim3(256), 0, c->stream, wn, n, total);
+  const int ntile = (int)((n + kScanTile - 1) / kScanTile);
+  LoadF64 lf{wn};
+  StoreF64 sf{c->cdf_approx};
+  hipLaunchKernelGGL((scan_reduce_kernel<double, LoadF64>), dim3(ntile), dim3(kScanBlock), 0, c->stream, lf, n,
+                     (double*)c->blk_a);
+  hipLaunchKernelGGL((scan_blocks_kernel<double>), dim3(1), dim3(kScanBlock), 0, c->stream, (double*)c->blk_a, ntile);
+  hipLaunchKernelGGL((scan_apply_kernel<double, LoadF64, StoreF64>), dim3(ntile), dim3(kScanBlock), 0, c->stream, lf,
+                     sf, n, (const double*)c->blk_a);
+  ClassifyLoader cl{c->cdf_approx, wn, first_index, approx_offset};
+  StoreKF sk{(unsigned long long*)c->kscan, c->fscan, (IrrRecord*)c->irr, wn, first_index};
+  hipLaunchKernelGGL((scan_reduce_kernel<KF, ClassifyLoader>), dim3(ntile), dim3(kScanBlock), 0, c->stream, cl, n,
+                     (KF*)c->blk_b);
+  hipLaunchKernelGGL((scan_blocks_kernel<KF>), dim3(1), dim3(kScanBlock), 0, c->stream, (KF*)c->blk_b, ntile);
+  hipLaunchKernelGGL((scan_apply_kernel<KF, ClassifyLoader, StoreKF>), dim3(ntile), dim3(kScanBlock), 0, c->stream, cl,
+                     sk, n, (const KF*)c->blk_b);
+  MCL_HIP(c, hipGetLastError());
+  return MCLHIP_OK;
+}
+
+// replay the GLOBAL record list (already on the device in d_records, global integer prefixes)
+// and turn this rank's integer prefixes into exact running sums
+int launch_shard_finalize(mclhip_ctx* c, const void* d_records, int64_t nrec, void* d_bases, uint64_t P_off,
+                          uint32_t F_off) {
+  const int64_t n = c->M;
+  const unsigned g = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(replay_kernel, dim3(1), dim3(64), 0, c->stream, (const IrrRecord*)d_records,
+                     (const unsigned int*)nullptr, n, nrec, (RunBase*)d_bases);
+  hipLaunchKernelGGL(finalize_cdf_kernel, dim3(g), dim3(256), 0, c->stream, (const unsigned long long*)c->kscan,
+                     c->fscan, (const RunBase*)d_bases, n, (unsigned long long)P_off, (unsigned int)F_off,
+                     c->cdf_exact);
+  MCL_HIP(c, hipGetLastError());
+  return MCLHIP_OK;
+}
+
+// counts[j] = number of local running sums that are < U[j]
+__global__ void count_below_kernel(const double* __restrict__ cdf, int64_t n, const double* __restrict__ U, int nu,
+                                   int64_t* __restrict__ counts) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nu) return;
+  const double u = U[j];
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (u > cdf[mid]) lo = mid + 1; else hi = mid;
+  }
+  counts[j] = lo;
+}
+
+int launch_count_below(mclhip_ctx* c, const double* d_U, int nu, int64_t* d_counts) {
+  hipLaunchKernelGGL(count_below_kernel, dim3((nu + 63) / 64), dim3(64), 0, c->stream, c->cdf_exact, c->M, d_U, nu,
+                     d_counts);
+  MCL_HIP(c, hipGetLastError());
+  return MCLHIP_OK;
+}
+
+// rows of five doubles (x, y, theta, w, running sum) for local particles [lo, hi)
+template <typename T>
+__global__ void pack_rows_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ th,
+                                 const double* __restrict__ w, const double* __restrict__ cdf, int64_t lo, int64_t hi,
+                                 double* __restrict__ dst) {
+  int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= hi) return;
+  double* r = dst + (i - lo) * 5;
+  r[0] = (double)x[i];
+  r[1] = (double)y[i];
+  r[2] = (double)th[i];
+  r[3] = w[i];
+  r[4] = cdf[i];
+}
+
+int launch_pack_rows(mclhip_ctx* c, int64_t lo, int64_t hi, double* d_dst) {
+  if (hi <= lo) return MCLHIP_OK;
+  const int a = c->cur;
+  const unsigned g = (unsigned)((hi - lo + 255) / 256);
+  if (c->dtype == MCLHIP_F32)
+    hipLaunchKernelGGL(pack_rows_kernel<float>, dim3(g), dim3(256), 0, c->stream, (const float*)c->px[a],
+                       (const float*)c->py[a], (const float*)c->pth[a], c->w[a], c->cdf_exact, lo, hi, d_dst);
+  else
+    hipLaunchKernelGGL(pack_rows_kernel<double>, dim3(g), dim3(256), 0, c->stream, (const double*)c->px[a],
+                       (const double*)c->py[a], (const double*)c->pth[a], c->w[a], c->cdf_exact, lo, hi, d_dst);
+  MCL_HIP(c, hipGetLastError());
+  return MCLHIP_OK;
+}
+
+// resample this rank's global positions m = first_index + j from the received rows:
+// index = number of received running sums that are < U_m, clamped to the last row
+template <typename T>
+__global__ __launch_bounds__(256) void unpack_resample_kernel(const double* __restrict__ rows, int64_t L,
+                                                              int64_t first_index, int64_t m_total, int64_t n,
+                                                              double r, int64_t row0_global, T* __restrict__ x2,
+                                                              T* __restrict__ y2, T* __restrict__ th2,
+                                                              double* __restrict__ w2, int64_t* __restrict__ idx) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int64_t m = first_index + j;
+  const double U = r + ((double)m / (double)m_total);  // mc_localization.py:254
+  int64_t lo = 0, hi = L;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (U > rows[mid * 5 + 4]) lo = mid + 1; else hi = mid;
+  }
+  if (lo > L - 1) lo = L - 1;
+  const double* s = rows + lo * 5;
+  idx[j] = row0_global + lo;
+  x2[j] = (T)s[0];
+  y2[j] = (T)s[1];
+  th2[j] = (T)s[2];
+  w2[j] = s[3];
+}
+
+int launch_unpack_resample(mclhip_ctx* c, const double* d_rows, int64_t L, int64_t first_index, int64_t m_total,
+                           double r, int64_t row0_global) {
+  const int64_t n = c->M;
+  const int b = 1 - c->cur;
+  const unsigned g = (unsigned)((n + 255) / 256);
+  if (c->dtype == MCLHIP_F32)
+    hipLaunchKernelGGL(unpack_resample_kernel<float>, dim3(g), dim3(256), 0, c->stream, d_rows, L, first_index,
+                       m_total, n, r, row0_global, (float*)c->px[b], (float*)c->py[b], (float*)c->pth[b], c->w[b],
+                       c->idx);
+  else
+    hipLaunchKernelGGL(unpack_resample_kernel<double>, dim3(g), dim3(256), 0, c->stream, d_rows, L, first_index,
+                       m_total, n, r, row0_global, (double*)c->px[b], (double*)c->py[b], (double*)c->pth[b], c->w[b],
+                       c->idx);
+  MCL_HIP(c, hipGetLastError());
+  c->cur = b;
+  return MCLHIP_OK;
 }
 
 size_t irr_record_bytes() { return sizeof(IrrRecord); }

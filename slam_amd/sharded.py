@@ -1,13 +1,221 @@
-"""One filter over several GPUs: one process per GPU, contiguous particle ranges per rank,
-map and beam table replicated.  With a single rank this is the plain fused step."""
+"""One filter over several GPUs: one process per GPU, contiguous particle ranges per rank, map
+and beam table replicated.
+
+Only small per-rank results cross ranks as collectives -- the largest log-weight (all-reduce
+max), the sums of the 8192-element chunks (all-gather; every rank then adds them left to right,
+so the global sum is bit-equal to np.sum of the whole vector on every rank), the integer totals
+and the short irregular-record lists of the order-exact scan (all-gather), and the counts that
+turn the 2*world shard-boundary positions into global source indices (all-reduce sum) --
+followed by one all-to-all of contiguous row slices: since resample indices are monotone, the
+positions a rank owns draw from one contiguous range of source particles.
+
+The arithmetic of every step lives behind a `backend` (the C ABI in production); this file is
+the cross-rank bookkeeping, and it is the same code under RCCL (GPU tensors) and gloo (CPU
+tensors, used by the CPU tests and by multi-process tests that share one GPU).
+"""
+import numpy as np
+
 from . import _lib
+
+CHUNK = 8192
+
+
+class HipShardBackend:
+    """The per-rank operations on a `_lib.Context`."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def set_range(self, first_index, m_total):
+        self.ctx.shard_set(first_index, m_total)
+
+    def num_local(self):
+        return self.ctx.num_particles()
+
+    def sample(self, v, omega, dt, alpha, z_meas, noise_ints, seed, mode):
+        self.ctx.shard_sample(v, omega, dt, alpha, z_meas, noise_ints, seed, mode)
+
+    def max_logw(self):
+        return self.ctx.shard_max_logw()
+
+    def weights(self, mode, gmax):
+        return self.ctx.shard_weights(mode, gmax)
+
+    def scan(self, total, approx_offset):
+        return self.ctx.shard_scan(total, approx_offset)
+
+    def get_records(self, n):
+        return self.ctx.shard_get_records(n)
+
+    def finalize(self, all_records, p_off, f_off):
+        self.ctx.shard_finalize(all_records, p_off, f_off)
+
+    def count_below(self, U):
+        return self.ctx.shard_count_below(U)
+
+    def pack(self, lo, hi, rows):
+        """rows: torch tensor [n,5] float64 (GPU or CPU) that receives the packed slices."""
+        self.ctx.shard_pack(lo, hi, rows.data_ptr())
+
+    def unpack_resample(self, rows, L, r, row0_global, want_idx):
+        return self.ctx.shard_unpack_resample(rows.data_ptr(), L, r, row0_global, want_idx)
+
+    def step_single(self, v, omega, dt, alpha, z_meas, r, noise_ints, seed, mode, wait):
+        self.ctx.step(v, omega, dt, alpha, z_meas, r, noise_ints, seed, mode, wait=wait)
+
+
+class _Coll:
+    """The few collectives the filter needs, on GPU tensors under RCCL or CPU tensors under gloo."""
+
+    def __init__(self, dist, rank, world):
+        import torch
+        self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
+        self.backend = dist.get_backend()
+        self.dev = torch.device("cuda", torch.cuda.current_device()) if self.backend == "nccl" else torch.device("cpu")
+
+    def _t(self, a, dtype):
+        return self.torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(self.dev)
+
+    def allreduce_max(self, x):
+        t = self._t([x], self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.cpu()[0])
+
+    def allreduce_sum_i64(self, a):
+        t = self._t(a, self.torch.int64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+
+    def allgather_bytes(self, payload, max_len=None):
+        """Every rank's byte string, in rank order (lengths may differ)."""
+        torch = self.torch
+        n = self._t([len(payload)], torch.int64)
+        lens = [torch.zeros_like(n) for _ in range(self.world)]
+        self.dist.all_gather(lens, n)
+        lens = [int(x.cpu()[0]) for x in lens]
+        cap = max(max(lens), 1)
+        buf = np.zeros(cap, np.uint8)
+        buf[:len(payload)] = np.frombuffer(payload, np.uint8)
+        t = self._t(buf, torch.uint8)
+        outs = [torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(outs, t)
+        return [o.cpu().numpy()[:lens[i]].tobytes() for i, o in enumerate(outs)]
+
+    def rows(self, n):
+        return self.torch.empty((max(n, 1), 5), dtype=self.torch.float64, device=self.dev)
+
+    def all_to_all_rows(self, send, send_counts, recv_counts):
+        """Row slices to every rank (send_counts[d] rows to rank d, in order)."""
+        torch, dist = self.torch, self.dist
+        recv = self.rows(int(sum(recv_counts)))
+        if self.backend == "nccl":
+            dist.all_to_all_single(recv[:int(sum(recv_counts))], send[:int(sum(send_counts))],
+                                   [int(c) for c in recv_counts], [int(c) for c in send_counts])
+            torch.cuda.synchronize()
+            return recv
+        so = np.concatenate([[0], np.cumsum(send_counts)]).astype(int)
+        ro = np.concatenate([[0], np.cumsum(recv_counts)]).astype(int)
+        reqs = []
+        for peer in range(self.world):
+            if peer == self.rank:
+                if send_counts[peer]:
+                    recv[ro[peer]:ro[peer + 1]] = send[so[peer]:so[peer + 1]]
+                continue
+            if send_counts[peer]:
+                reqs.append(dist.isend(send[so[peer]:so[peer + 1]].contiguous(), peer))
+            if recv_counts[peer]:
+                reqs.append(dist.irecv(recv[ro[peer]:ro[peer + 1]], peer))
+        for q in reqs:
+            q.wait()
+        return recv
+
+
+def sequential_sum(values):
+    """Left-to-right float64 sum starting from 0.0 -- the order in which numpy adds chunk results."""
+    t = np.float64(0.0)
+    for v in np.asarray(values, np.float64):
+        t = t + v
+    return float(t)
 
 
 class ShardedFilter:
-    def __init__(self, ctx, dist, rank, world, m_local):
-        self.ctx, self.dist, self.rank, self.world, self.m_local = ctx, dist, rank, world, m_local
-        if world > 1:
-            raise NotImplementedError("multi-GPU exchange not built yet")
+    """Drives one MCL update per call over `world` ranks."""
 
-    def step(self, v, omega, dt, alpha, z_meas, r, seed):
-        self.ctx.step(v, omega, dt, alpha, z_meas, r, None, seed, _lib.W_LOG, wait=False)
+    def __init__(self, ctx_or_backend, dist, rank, world, m_local, weight_mode=_lib.W_LOG):
+        self.b = HipShardBackend(ctx_or_backend) if isinstance(ctx_or_backend, _lib.Context) else ctx_or_backend
+        self.dist, self.rank, self.world, self.mode = dist, rank, world, weight_mode
+        self.m_local = int(m_local)
+        self.last_idx = None
+        if world > 1:
+            self.coll = _Coll(dist, rank, world)
+            sizes = self.coll.allgather_bytes(np.int64(self.m_local).tobytes())
+            self.sizes = [int(np.frombuffer(s, np.int64)[0]) for s in sizes]
+            for s in self.sizes[:-1]:
+                if s % CHUNK:
+                    raise ValueError("every rank but the last must hold a multiple of %d particles" % CHUNK)
+            self.firsts = [int(x) for x in np.concatenate([[0], np.cumsum(self.sizes)])]
+            self.m_total = self.firsts[-1]
+            self.b.set_range(self.firsts[rank], self.m_total)
+        else:
+            self.sizes, self.firsts, self.m_total = [self.m_local], [0, self.m_local], self.m_local
+
+    def step(self, v, omega, dt, alpha, z_meas, r, seed=0, noise_ints=None, want_idx=False):
+        """r = (uniform draw) / M_total, identical on every rank."""
+        if self.world == 1:
+            self.b.step_single(v, omega, dt, alpha, z_meas, r, noise_ints, seed, self.mode, wait=want_idx)
+            return
+        b, co, rank, world = self.b, self.coll, self.rank, self.world
+        b.sample(v, omega, dt, alpha, z_meas, noise_ints, seed, self.mode)
+        gmax = co.allreduce_max(b.max_logw()) if self.mode == _lib.W_LOG else 0.0
+        # global sum in numpy's order: chunk sums of all ranks, added left to right
+        chunks = b.weights(self.mode, gmax)
+        all_chunks = [np.frombuffer(x, np.float64) for x in co.allgather_bytes(chunks.tobytes())]
+        total = sequential_sum(np.concatenate(all_chunks))
+        self.total = total
+        below = float(np.sum(np.concatenate(all_chunks[:rank]))) if rank else 0.0
+        with np.errstate(divide="ignore", invalid="ignore"):
+            approx_offset = float(np.float64(below) / np.float64(total))
+        # local half of the order-exact scan, then the global record list
+        k_total, nrec = b.scan(total, approx_offset)
+        recs = b.get_records(nrec)
+        head = np.array([k_total, nrec], np.uint64).tobytes()
+        parts = co.allgather_bytes(head + recs.tobytes())
+        k_tot = [int(np.frombuffer(p[:16], np.uint64)[0]) for p in parts]
+        n_rec = [int(np.frombuffer(p[:16], np.uint64)[1]) for p in parts]
+        p_off = [0] * world
+        f_off = [0] * world
+        for s in range(1, world):
+            p_off[s] = (p_off[s - 1] + k_tot[s - 1]) & 0xFFFFFFFFFFFFFFFF
+            f_off[s] = f_off[s - 1] + n_rec[s - 1]
+        glob = []
+        for s, p in enumerate(parts):
+            rs = np.frombuffer(p[16:], _lib.Context.RECORD_DTYPE).copy()
+            rs["P"] = rs["P"] + np.uint64(p_off[s])  # wraps modulo 2^64 like the device prefix
+            glob.append(rs)
+        b.finalize(np.concatenate(glob), p_off[rank], f_off[rank])
+        # global source index of the first and last position of every rank
+        M = self.m_total
+        m_edge = []
+        for d in range(world):
+            m_edge += [self.firsts[d], self.firsts[d + 1] - 1]
+        U = np.array([r + (m / M) for m in m_edge], np.float64)   # mc_localization.py:254
+        gidx = np.minimum(co.allreduce_sum_i64(b.count_below(U)), M - 1)
+        glo, ghi = gidx[0::2], gidx[1::2]
+        my_lo, my_hi = self.firsts[rank], self.firsts[rank + 1] - 1
+        lo, hi, send_counts = [], [], []
+        for d in range(world):          # what this rank sends to d
+            a, z = max(int(glo[d]), my_lo), min(int(ghi[d]), my_hi)
+            n = max(0, z - a + 1)
+            send_counts.append(n)
+            lo.append(a - my_lo if n else 0)
+            hi.append(z - my_lo + 1 if n else 0)
+        recv_counts = []
+        for s in range(world):          # what this rank receives from s
+            a, z = max(int(glo[rank]), self.firsts[s]), min(int(ghi[rank]), self.firsts[s + 1] - 1)
+            recv_counts.append(max(0, z - a + 1))
+        send = co.rows(sum(send_counts))
+        if sum(send_counts):
+            b.pack(lo, hi, send)
+        recv = co.all_to_all_rows(send, send_counts, recv_counts)
+        L = int(sum(recv_counts))
+        self.last_idx = b.unpack_resample(recv, L, r, int(glo[rank]), want_idx)

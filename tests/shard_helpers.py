@@ -1,0 +1,129 @@
+"""Helpers for the multi-rank tests: a numpy stand-in for the per-rank device operations and a
+process launcher (gloo, 127.0.0.1)."""
+import os
+import socket
+import sys
+import traceback
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+REC = np.dtype([("i", "<i8"), ("w", "<f8"), ("P", "<u8")])
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def synthetic_logw(X):
+    """A deterministic stand-in for the beam likelihood: any function of the pose will do for
+    testing the cross-rank bookkeeping."""
+    return -40.0 * ((X[:, 0] - 3.0) ** 2 + (X[:, 1] - 4.0) ** 2) - 3.0 * np.cos(X[:, 2]) ** 2
+
+
+class NumpyShardBackend:
+    """Per-rank operations in numpy.  Every element is declared an irregular record, which is a
+    valid (if slow) classification: the running sum is then rebuilt by the plain sequential
+    cumulative sum over the global record list."""
+
+    def __init__(self, X_local):
+        self.X = np.array(X_local, np.float64)
+        self.w = np.ones(len(self.X))
+        self.first, self.m_total = 0, len(self.X)
+
+    def set_range(self, first_index, m_total):
+        self.first, self.m_total = first_index, m_total
+
+    def num_local(self):
+        return len(self.X)
+
+    def sample(self, v, omega, dt, alpha, z_meas, noise_ints, seed, mode):
+        from oracle import mcl_oracle as O
+        grid = np.full((200, 200), 255, np.uint8)
+        self.X, pm = O.motion(self.X, (v, omega), dt, grid, noise_ints, tuple(alpha))
+        self.logw = synthetic_logw(self.X)
+        self.w = np.exp(self.logw) * pm
+
+    def max_logw(self):
+        return float(np.max(self.logw))
+
+    def weights(self, mode, gmax):
+        if mode == 1:
+            self.w = np.exp(self.logw - gmax)
+        return np.array([np.sum(self.w[s:s + 8192]) for s in range(0, len(self.w), 8192)])
+
+    def scan(self, total, approx_offset):
+        self.w = self.w / total
+        return 0, len(self.w)
+
+    def get_records(self, n):
+        r = np.zeros(n, REC)
+        r["i"] = self.first + np.arange(n)
+        r["w"] = self.w
+        return r
+
+    def finalize(self, all_records, p_off, f_off):
+        c = np.cumsum(all_records["w"])
+        self.cdf = c[f_off:f_off + len(self.w)]
+
+    def count_below(self, U):
+        return np.searchsorted(self.cdf, U, side="left").astype(np.int64)
+
+    def pack(self, lo, hi, rows):
+        out = []
+        for a, z in zip(lo, hi):
+            out.append(np.concatenate([self.X[a:z], self.w[a:z, None], self.cdf[a:z, None]], 1))
+        out = np.concatenate(out, 0)
+        rows[:len(out)] = __import__("torch").from_numpy(out)
+
+    def unpack_resample(self, rows, L, r, row0_global, want_idx):
+        R = rows[:L].numpy()
+        m = self.first + np.arange(len(self.X))
+        U = r + (m / self.m_total)
+        j = np.minimum(np.searchsorted(R[:, 4], U, side="left"), L - 1)
+        self.X = R[j, :3].copy()
+        self.w = R[j, 3].copy()
+        return row0_global + j
+
+
+def run_ranks(fn, world, *args):
+    """fn(rank, world, port, queue, *args) in `world` processes; returns the per-rank results."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_entry, args=(fn, r, world, port, q) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = {}
+    for _ in range(world):
+        r, val = q.get(timeout=300)
+        out[r] = val
+    for p in procs:
+        p.join(60)
+    for r in range(world):
+        if isinstance(out[r], str) and out[r].startswith("ERROR"):
+            raise AssertionError("rank %d failed:\n%s" % (r, out[r]))
+    return [out[r] for r in range(world)]
+
+
+def _entry(fn, rank, world, port, q, *args):
+    try:
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        val = fn(rank, world, dist, *args)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, val))
+    except Exception:
+        q.put((rank, "ERROR " + traceback.format_exc()))
