@@ -2,6 +2,7 @@
 // <-> device staging and the order in which the stage kernels are enqueued.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <vector>
@@ -42,6 +43,7 @@ RayParams make_ray_params(const mclhip_ctx* c) {
   P.lambda = c->lambda;
   P.w_hit = c->w4[0]; P.w_short = c->w4[1]; P.w_max = c->w4[2]; P.w_rand = c->w4[3];
   P.p_rand = 1 / c->z_max;                               // range_sensor.py:64
+  { const char* d = getenv("MCLHIP_ABLATE"); P.dbg = d ? atoi(d) : 0; }
   return P;
 }
 

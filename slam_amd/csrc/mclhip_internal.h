@@ -43,6 +43,7 @@ struct RayParams {
   double lambda;
   double w_hit, w_short, w_max, w_rand;
   double p_rand;         // 1/z_max
+  int dbg;               // profiling ablations (0 in production)
 };
 
 struct MotionParams {

@@ -29,6 +29,7 @@ constexpr int kTakeMax = 8;         // set bits a lane contributes per round
 constexpr double kEdgeEps = 1e-5;   // float32 bearing is trusted farther than this from a sector edge
 constexpr double kTwoPi = 6.283185307179586;  // == np.pi*2.0
 constexpr int kWavesPerBlock = 4;
+constexpr int kGroup = 8;           // beams examined per step of the matching loop
 
 // ---- cross-lane helpers on the DPP path (no LDS round trip) ----------------
 #define MCL_DPP_I32(old, v, ctrl, rmask) __builtin_amdgcn_update_dpp((old), (v), (ctrl), (rmask), 0xf, false)
@@ -79,12 +80,14 @@ __global__ __launch_bounds__(256) void raycast_kernel(RayParams P, const T* __re
   unsigned long long* s_rmin_all = reinterpret_cast<unsigned long long*>(s_el + B);
   unsigned long long* s_aux_all = s_rmin_all + (size_t)kWavesPerBlock * B;
   unsigned int* s_list_all = reinterpret_cast<unsigned int*>(s_aux_all + (size_t)((STAGE || PRODUCT) ? kWavesPerBlock * B : 0));
-  unsigned short* s_perm = reinterpret_cast<unsigned short*>(s_list_all + (size_t)kWavesPerBlock * kListCap);
+  float* s_relf = reinterpret_cast<float*>(s_list_all + (size_t)kWavesPerBlock * kListCap);  // [B] float32(sorted angle - smallest)
+  unsigned short* s_perm = reinterpret_cast<unsigned short*>(s_relf + B);
   unsigned short* s_lut = s_perm + B;
   unsigned short* s_ring = s_lut + NB;                            // [n_ring] (dty+128) << 8 | (dtx+128)
 
   for (int k = threadIdx.x; k < B; k += blockDim.x) {
     s_ts[k] = P.tab_sorted[k];
+    s_relf[k] = (float)(P.tab_sorted[k] - P.ts_min);
     s_perm[k] = P.perm[k];
     if (!STAGE) {
       s_zt[k] = P.zt[k];
@@ -108,6 +111,8 @@ __global__ __launch_bounds__(256) void raycast_kernel(RayParams P, const T* __re
   const double span = P.ts_max - P.ts_min;
   const double reach = P.half + 2.0 * kEdgeEps;   // candidate window half-width
   const double inv_two_pi = 1.0 / kTwoPi;
+  const float reachf = (float)reach, inv_bwf = (float)P.inv_bw;
+  const float sure_in = (float)(P.half - kEdgeEps), sure_out = (float)(P.half + kEdgeEps);
 
   for (int64_t p = (int64_t)blockIdx.x * kWavesPerBlock + wv; p < n; p += (int64_t)gridDim.x * kWavesPerBlock) {
     const double x = (double)xs[p], y = (double)ys[p], th = (double)ths[p];
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(256) void raycast_kernel(RayParams P, const T* __re
     const bool pose_ok = (fabs(fxc) < 1.0e6) && (fabs(fyc) < 1.0e6);
     const int tcx = pose_ok ? ((int)floor(fxc)) >> 3 : 0;
     const int tcy = pose_ok ? ((int)floor(fyc)) >> 3 : 0;
-    const int nt = (pose_ok && fabs(th) < INFINITY) ? P.n_ring : 0;  // NaN / infinite headings match no beam
+    const int nt = (pose_ok && fabs(th) < INFINITY && !(P.dbg & 4)) ? P.n_ring : 0;  // NaN / infinite headings match no beam
     const float xf = (float)x, yf = (float)y;
 
     for (int phase = 0; phase < (STAGE ? 2 : 1); ++phase) {
@@ -139,11 +144,12 @@ __global__ __launch_bounds__(256) void raycast_kernel(RayParams P, const T* __re
           const double oy = (double)((float)row * P.res_yf);
           const double dx = ox - x, dy = oy - y;              // :124-125, float64
           const double r2 = dx * dx + dy * dy;                // :126
-          if (valid && r2 <= P.r2max) {                       // :127
-            float af = atan2f((float)dy, (float)dx);
+          if (valid && r2 <= P.r2max && !(P.dbg & 1)) {                       // :127
+            float af = (P.dbg & 8) ? (float)dy : atan2f((float)dy, (float)dx);
             if (af < 0.0f) af += 6.2831855f;
             const double aa = (double)af;
             const unsigned long long r2bits = (unsigned long long)__double_as_longlong(r2);
+            const unsigned long long cellbits = (unsigned long long)((unsigned int)row * (unsigned int)P.W + (unsigned int)col);
             // beams whose table angle lies within `reach` of aa - th + c*2pi, c in {-1, 0, 1}
             const double psi = (aa - th) - P.ts_min;
             int c_lo = (int)ceil((-reach - psi) * inv_two_pi);
@@ -154,43 +160,58 @@ __global__ __launch_bounds__(256) void raycast_kernel(RayParams P, const T* __re
             bool have_exact = false;
 #pragma unroll 1
             for (int c = c_lo; c <= c_hi; ++c) {
-              const double centre = psi + (double)c * kTwoPi;   // relative to ts_min
-              const double lo = centre - reach, hi = centre + reach;
-              int k = 0;
-              if (lo > 0.0) {
-                int bkt = (int)(lo * P.inv_bw) - 1;
+              // window centre relative to the smallest table angle; small whenever the window can
+              // hold a beam, so float32 is enough for everything but the edge cases
+              const float centref = (float)(psi + (double)c * kTwoPi);
+              const float lof = centref - reachf;
+              int k0 = 0;
+              if (lof > 0.0f) {
+                int bkt = (int)(lof * inv_bwf) - 1;
                 bkt = bkt < 0 ? 0 : (bkt > NB - 1 ? NB - 1 : bkt);
-                k = s_lut[bkt];
+                k0 = s_lut[bkt];
               }
-              const double wrap = (c == 0) ? 0.0 : kTwoPi;
+              // beams are visited eight at a time: all sixteen LDS reads of a group are issued
+              // before the first use, so their latency is paid once per group, not once per beam
 #pragma unroll 1
-              for (; k < B; ++k) {
-                const double tk = s_ts[k];
-                const double rel = tk - P.ts_min;
-                if (rel < lo) continue;
-                if (rel > hi) break;
-                if (!(STAGE && phase == 1) && r2bits >= rmin[k]) continue;  // not closer than this beam's minimum
-                const double beta = tk + th;                    // :143
-                const double dd = fabs(beta - aa);              // :148 with the float32 bearing
-                const double edge = fabs(dd - wrap);            // distance from the sector axis (or its 2pi image)
-                bool ok = edge <= P.half - kEdgeEps;
-                if (!ok && edge < P.half + kEdgeEps) {          // too close to an edge: exact bearing
+              for (int kb = k0; kb < B; kb += kGroup) {
+                float e[kGroup];
+                unsigned long long rm[kGroup];
+#pragma unroll
+                for (int j = 0; j < kGroup; ++j) {
+                  const int kk = (kb + j < B) ? kb + j : B - 1;
+                  e[j] = s_relf[kk] - centref;                  // bearing offset from the beam's axis
+                  rm[j] = rmin[kk];
+                }
+                unsigned int edge_mask = 0u;
+                bool beyond = false;
+#pragma unroll
+                for (int j = 0; j < kGroup; ++j) {
+                  const float ae = fabsf(e[j]);
+                  const bool live = (kb + j < B) && ((STAGE && phase == 1) ? (rm[j] == r2bits) : (r2bits < rm[j]));
+                  beyond = beyond || (e[j] > reachf);
+                  if (live && ae <= sure_in) {
+                    if (!STAGE || phase == 0) atomicMin(&rmin[kb + j], r2bits);
+                    else atomicMin(&aux[kb + j], cellbits);     // lowest row-major index among equally near cells
+                  } else if (live && ae < sure_out) {
+                    edge_mask |= 1u << j;                       // too close to a sector edge for float32
+                  }
+                }
+                while (edge_mask) {                             // rare: exact float64 bearing
+                  const int j = __ffs((int)edge_mask) - 1;
+                  edge_mask &= edge_mask - 1u;
                   if (!have_exact) {
                     a_exact = atan2(dy, dx);                    // :133
                     if (a_exact < 0.0) a_exact += kTwoPi;       // :134-135
                     have_exact = true;
                   }
+                  const double beta = s_ts[kb + j] + th;        // :143
                   const double de = fabs(beta - a_exact);       // :148
-                  ok = (de <= P.half) || (de >= P.two_pi_lo && de <= P.two_pi_hi);  // :149
-                }
-                if (ok) {
-                  if (!STAGE || phase == 0) {
-                    atomicMin(&rmin[k], r2bits);
-                  } else if (rmin[k] == r2bits) {
-                    // lowest row-major index among equally near cells
-                    atomicMin(&aux[k], (unsigned long long)((unsigned int)row * (unsigned int)P.W + (unsigned int)col));
+                  if ((de <= P.half) || (de >= P.two_pi_lo && de <= P.two_pi_hi)) {  // :149
+                    if (!STAGE || phase == 0) atomicMin(&rmin[kb + j], r2bits);
+                    else atomicMin(&aux[kb + j], cellbits);
                   }
                 }
+                if (beyond) break;
               }
             }
           }
@@ -233,13 +254,16 @@ __global__ __launch_bounds__(256) void raycast_kernel(RayParams P, const T* __re
           const int tot = __builtin_amdgcn_readlane(incl, 63);
           if (count + tot > kListCap) drain(false);
           int pos = count + incl - take;
+          unsigned int blo = (unsigned int)bits, bhi = (unsigned int)(bits >> 32);
+          const unsigned int origin = ((unsigned int)(ty * 8) << 16) | (unsigned int)(tx * 8);
           for (int q = 0; q < take; ++q) {
-            const int bit = __ffsll((long long)bits) - 1;
-            bits &= bits - 1ull;
-            const unsigned int row = (unsigned int)(ty * 8 + (bit >> 3));
-            const unsigned int col = (unsigned int)(tx * 8 + (bit & 7));
-            list[pos++] = (row << 16) | col;
+            const bool low = blo != 0u;
+            const unsigned int word = low ? blo : bhi;
+            const int bit = __ffs((int)word) - 1 + (low ? 0 : 32);
+            if (low) blo &= blo - 1u; else bhi &= bhi - 1u;
+            list[pos++] = origin + (((unsigned int)(bit >> 3)) << 16) + (unsigned int)(bit & 7);
           }
+          bits = ((unsigned long long)bhi << 32) | blo;
           count += tot;
         }
       }
@@ -262,7 +286,7 @@ __global__ __launch_bounds__(256) void raycast_kernel(RayParams P, const T* __re
       // partial product (sum of logs == log of product; 16 factors >= 1e-3 cannot underflow)
       double ls = 0.0, prod = 1.0;
       int nfac = 0;
-      for (int k = lane; k < B; k += 64) {
+      for (int k = lane; k < ((P.dbg & 2) ? 0 : B); k += 64) {
         const double r2 = __longlong_as_double((long long)rmin[k]);
         const double zd = sqrt(r2);
         const double ztd = s_zt[k];
@@ -314,7 +338,8 @@ static size_t ray_lds_bytes(int B, int NB, int n_ring, bool aux) {
   size_t s = (size_t)3 * B * sizeof(double);
   s += (size_t)kWavesPerBlock * B * sizeof(unsigned long long) * (aux ? 2 : 1);
   s += (size_t)kWavesPerBlock * kListCap * sizeof(unsigned int);
-  s += ((size_t)B + NB + n_ring) * sizeof(unsigned short);
+  s += ((size_t)B + NB + n_ring + 2) * sizeof(unsigned short);
+  s += (size_t)B * sizeof(float);
   return (s + 15) & ~(size_t)15;
 }
 

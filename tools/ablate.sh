@@ -1,0 +1,6 @@
+#!/bin/bash
+# timing of the sector-query kernel with parts switched off (profiling aid)
+for a in 0 1 2 3 4 6 7 8; do
+  echo -n "ablate=$a  "
+  MCLHIP_ABLATE=$a timeout -k 10 120 python bench.py --steps 5 --warmup 1 --cpu-particles 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['kernel_ms'])"
+done
