@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmclhip.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("MCLHIP_LIBNAME", "libmclhip.so"))
 
 F32, F64 = 0, 1
 W_PRODUCT, W_LOG = 0, 1

@@ -24,8 +24,7 @@
 
 namespace mcl {
 
-constexpr int kListCap = 576;       // per-wave obstacle list: 512 per round + a carried remainder < 64
-constexpr int kTakeMax = 8;         // set bits a lane contributes per round
+constexpr int kListCap = 256;       // per-wave obstacle list; drained in batches of 64 before it can overflow
 constexpr double kEdgeEps = 1e-5;   // float32 bearing is trusted farther than this from a sector edge
 constexpr double kTwoPi = 6.283185307179586;  // == np.pi*2.0
 constexpr int kWavesPerBlock = 4;
@@ -65,8 +64,11 @@ __device__ inline double wave_sum(double v) {
                               (unsigned int)__builtin_amdgcn_readlane((int)__double_as_longlong(v), 63));
 }
 
+#ifndef MCL_RAY_WAVES
+#define MCL_RAY_WAVES 3
+#endif
 template <typename T, bool STAGE, bool PRODUCT>
-__global__ __launch_bounds__(256) void raycast_kernel(RayParams P, const T* __restrict__ xs, const T* __restrict__ ys,
+__global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(RayParams P, const T* __restrict__ xs, const T* __restrict__ ys,
                                                       const T* __restrict__ ths, const uint8_t* __restrict__ pm,
                                                       int64_t n, double* __restrict__ w_out,
                                                       double* __restrict__ logw_out, double* __restrict__ ranges_out,
@@ -105,8 +107,8 @@ __global__ __launch_bounds__(256) void raycast_kernel(RayParams P, const T* __re
   unsigned int* const list = s_list_all + (size_t)wv * kListCap;  // packed (row << 16 | col)
 
   const unsigned long long r2max_bits = (unsigned long long)__double_as_longlong(P.r2max);
-  const float cull_r = (float)(P.z_max + 2.0 * (P.res_x + P.res_y));
-  const float cull_r2 = cull_r * cull_r;
+  const float disk_r = (float)(P.z_max * (1.0 + 1e-5) + 0.02 * (P.res_x < P.res_y ? P.res_x : P.res_y));
+  const float disk_r2 = disk_r * disk_r;
   const double neg_half_inv_s2 = -0.5 / P.sigma2;
   const double span = P.ts_max - P.ts_min;
   const double reach = P.half + 2.0 * kEdgeEps;   // candidate window half-width
@@ -127,6 +129,31 @@ __global__ __launch_bounds__(256) void raycast_kernel(RayParams P, const T* __re
     const int tcy = pose_ok ? ((int)floor(fyc)) >> 3 : 0;
     const int nt = (pose_ok && fabs(th) < INFINITY && !(P.dbg & 4)) ? P.n_ring : 0;  // NaN / infinite headings match no beam
     const float xf = (float)x, yf = (float)y;
+    const unsigned int lane_cell = ((unsigned int)(lane >> 3) << 16) | (unsigned int)(lane & 7);
+
+    // (row << 16) | col of the first cell of this lane's tile in the pass starting at ring entry `base`
+    auto tile_origin = [&](int base) -> unsigned int {
+      const int t = base + lane;
+      if (t >= nt) return 0u;
+      const unsigned int rg = s_ring[t];
+      const int ty = tcy + (int)(rg >> 8) - 128, tx = tcx + (int)(rg & 0xffu) - 128;
+      return ((unsigned int)(ty * 8) << 16) | ((unsigned int)(tx * 8) & 0xffffu);
+    };
+    // obstacle bits of that tile; 0 outside the map or when no cell of the tile can be in range
+    auto load_tile = [&](int base) -> unsigned long long {
+      const int t = base + lane;
+      if (t >= nt) return 0ull;
+      const unsigned int rg = s_ring[t];
+      const int ty = tcy + (int)(rg >> 8) - 128, tx = tcx + (int)(rg & 0xffu) - 128;
+      if (ty < 0 || ty >= P.TH || tx < 0 || tx >= P.TW) return 0ull;
+      // nearest point of the tile's cell-centre rectangle to the particle
+      const float cx0 = (float)(tx * 8) * P.res_xf, cx1 = (float)(tx * 8 + 7) * P.res_xf;
+      const float cy0 = (float)(ty * 8) * P.res_yf, cy1 = (float)(ty * 8 + 7) * P.res_yf;
+      const float ddx = xf < cx0 ? cx0 - xf : (xf > cx1 ? xf - cx1 : 0.0f);
+      const float ddy = yf < cy0 ? cy0 - yf : (yf > cy1 ? yf - cy1 : 0.0f);
+      if (ddx * ddx + ddy * ddy > disk_r2) return 0ull;
+      return P.obst[(size_t)ty * P.TW + tx];
+    };
 
     for (int phase = 0; phase < (STAGE ? 2 : 1); ++phase) {
       int count = 0;  // wave-uniform number of list entries
@@ -230,41 +257,31 @@ __global__ __launch_bounds__(256) void raycast_kernel(RayParams P, const T* __re
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       };
 
+      // Tiles nearest-first, 64 per pass (one per lane).  The non-empty ones are then expanded one
+      // tile at a time with lane = cell of the tile: a cell is kept when its bit is set and a
+      // float32 distance test (a little generous; the exact test follows in drain) puts it within
+      // z_max, and the kept cells are appended to the list in lane order.
+      unsigned long long bits_next = load_tile(0);
       for (int base = 0; base < nt; base += 64) {
-        const int t = base + lane;
-        unsigned long long bits = 0ull;
-        int ty = 0, tx = 0;
-        if (t < nt) {
-          const unsigned int rg = s_ring[t];
-          ty = tcy + (int)(rg >> 8) - 128;
-          tx = tcx + (int)(rg & 0xffu) - 128;
-          if (ty >= 0 && ty < P.TH && tx >= 0 && tx < P.TW) {
-            // nearest point of the tile's cell-centre rectangle to the particle
-            const float cx0 = (float)(tx * 8) * P.res_xf, cx1 = (float)(tx * 8 + 7) * P.res_xf;
-            const float cy0 = (float)(ty * 8) * P.res_yf, cy1 = (float)(ty * 8 + 7) * P.res_yf;
-            const float ddx = xf < cx0 ? cx0 - xf : (xf > cx1 ? xf - cx1 : 0.0f);
-            const float ddy = yf < cy0 ? cy0 - yf : (yf > cy1 ? yf - cy1 : 0.0f);
-            if (ddx * ddx + ddy * ddy <= cull_r2) bits = P.obst[(size_t)ty * P.TW + tx];
-          }
-        }
-        while (__ballot(bits != 0ull) != 0ull) {
-          const int pc = __popcll(bits);
-          const int take = pc < kTakeMax ? pc : kTakeMax;
-          const int incl = wave_incl_scan(take);
-          const int tot = __builtin_amdgcn_readlane(incl, 63);
-          if (count + tot > kListCap) drain(false);
-          int pos = count + incl - take;
-          unsigned int blo = (unsigned int)bits, bhi = (unsigned int)(bits >> 32);
-          const unsigned int origin = ((unsigned int)(ty * 8) << 16) | (unsigned int)(tx * 8);
-          for (int q = 0; q < take; ++q) {
-            const bool low = blo != 0u;
-            const unsigned int word = low ? blo : bhi;
-            const int bit = __ffs((int)word) - 1 + (low ? 0 : 32);
-            if (low) blo &= blo - 1u; else bhi &= bhi - 1u;
-            list[pos++] = origin + (((unsigned int)(bit >> 3)) << 16) + (unsigned int)(bit & 7);
-          }
-          bits = ((unsigned long long)bhi << 32) | blo;
-          count += tot;
+        const unsigned long long bits = bits_next;
+        const unsigned int my_origin = tile_origin(base);
+        if (base + 64 < nt) bits_next = load_tile(base + 64);   // in flight while this pass is expanded
+        unsigned long long nz = __ballot(bits != 0ull);
+        while (nz != 0ull) {
+          const int src = __ffsll((long long)nz) - 1;
+          nz &= nz - 1ull;
+          const unsigned int tlo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)bits, src);
+          const unsigned int thi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(bits >> 32), src);
+          const unsigned int org = (unsigned int)__builtin_amdgcn_readlane((int)my_origin, src);
+          const unsigned int word = lane < 32 ? tlo : thi;
+          const unsigned int entry = org + lane_cell;            // (row << 16) | col of this lane's cell
+          const float cdx = (float)(entry & 0xffffu) * P.res_xf - xf;
+          const float cdy = (float)(entry >> 16) * P.res_yf - yf;
+          const bool keep = ((word >> (lane & 31)) & 1u) && (cdx * cdx + cdy * cdy <= disk_r2);
+          const unsigned long long km = __ballot(keep);
+          if (keep) list[count + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)km, 0u))] = entry;
+          count += __popcll(km);
+          if (count + 64 > kListCap) drain(false);
         }
       }
       drain(true);
