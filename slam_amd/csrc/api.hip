@@ -24,7 +24,8 @@ size_t kf_bytes();
 
 RayParams make_ray_params(const mclhip_ctx* c) {
   RayParams P;
-  P.obst = c->obst;
+  P.tile_off = c->tile_off;
+  P.cells = c->cells;
   P.TW = c->TW; P.TH = c->TH; P.W = c->W; P.H = c->H;
   P.res_xf = (float)c->res_x; P.res_yf = (float)c->res_y;
   P.res_x = c->res_x; P.res_y = c->res_y;
@@ -241,7 +242,7 @@ void mclhip_destroy(mclhip_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  void* ptrs[] = {c->obst, c->freeb, c->tab_sorted, c->tab_orig, c->perm, c->lut, c->zt, c->etalam, c->zmeas_stage, c->ring,
+  void* ptrs[] = {c->obst, c->freeb, c->tile_off, c->cells, c->tab_sorted, c->tab_orig, c->perm, c->lut, c->zt, c->etalam, c->zmeas_stage, c->ring,
                   c->px[0], c->px[1], c->py[0], c->py[1], c->pth[0], c->pth[1], c->w[0], c->w[1], c->logw, c->pm,
                   c->sx, c->sy, c->sth, c->sw, c->chunk_sums, c->scal, c->cdf_approx, c->cdf_exact, c->kscan,
                   c->fscan, c->blk_a, c->blk_b, c->irr, c->bases, c->idx, c->noise, c->counters, c->g_records, c->g_bases,
@@ -265,6 +266,27 @@ int mclhip_set_map(mclhip_ctx* c, const uint8_t* map, int H, int W, double res_x
   const size_t nt = (size_t)c->TH * c->TW;
   MCL_TRY(dev_alloc(c, &c->obst, nt * sizeof(uint64_t)));
   MCL_TRY(dev_alloc(c, &c->freeb, nt * sizeof(uint64_t)));
+  // per-tile obstacle lists (mc_localization.py:61-71 keeps one flat list; the kernels want the
+  // cells grouped by 8x8 tile so that a particle only touches the tiles around it)
+  {
+    std::vector<uint32_t> off(nt + 1, 0), cells;
+    cells.reserve((size_t)H * W / 16);
+    for (int ty = 0; ty < c->TH; ++ty)
+      for (int tx = 0; tx < c->TW; ++tx) {
+        off[(size_t)ty * c->TW + tx] = (uint32_t)cells.size();
+        const int r1 = std::min(ty * 8 + 8, H), c1 = std::min(tx * 8 + 8, W);
+        for (int r = ty * 8; r < r1; ++r)
+          for (int q = tx * 8; q < c1; ++q)
+            if (map[(size_t)r * W + q] == 0) cells.push_back(((uint32_t)r << 16) | (uint32_t)q);
+      }
+    off[nt] = (uint32_t)cells.size();
+    c->n_obstacles = (int64_t)cells.size();
+    MCL_TRY(dev_alloc(c, &c->tile_off, (nt + 1) * sizeof(uint32_t)));
+    MCL_TRY(dev_alloc(c, &c->cells, cells.size() * sizeof(uint32_t)));
+    MCL_HIP(c, hipMemcpy(c->tile_off, off.data(), (nt + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (!cells.empty())
+      MCL_HIP(c, hipMemcpy(c->cells, cells.data(), cells.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
   uint8_t* d_map = nullptr;
   MCL_HIP(c, hipMalloc((void**)&d_map, (size_t)H * W));
   hipError_t e = hipMemcpyAsync(d_map, map, (size_t)H * W, hipMemcpyHostToDevice, c->stream);

@@ -21,7 +21,8 @@ constexpr int kScanTile = kScanBlock * kScanItems;
 
 // Everything the sector-query kernel needs about the map and the sensor.
 struct RayParams {
-  const uint64_t* obst;  // obstacle bit plane, one 64-bit word per 8x8-cell tile, row-major tiles
+  const uint32_t* tile_off;  // [TH*TW + 1] start of each 8x8-cell tile's obstacle list in cells[]
+  const uint32_t* cells;     // obstacle cells grouped by tile (row-major tiles, row-major inside): row << 16 | col
   int TW, TH, W, H;
   float res_xf, res_yf;  // float32 cell size: cell-centre coordinates are float32 products
   double res_x, res_y;
@@ -68,8 +69,11 @@ struct mclhip_ctx {
   // map
   int H = 0, W = 0, TH = 0, TW = 0;
   double res_x = 0, res_y = 0;
-  uint64_t* obst = nullptr;
-  uint64_t* freeb = nullptr;
+  uint64_t* obst = nullptr;     // obstacle bit plane (8x8-cell tiles)
+  uint64_t* freeb = nullptr;    // free-cell bit plane
+  uint32_t* tile_off = nullptr; // per-tile obstacle lists: offsets ...
+  uint32_t* cells = nullptr;    // ... and entries
+  int64_t n_obstacles = 0;
 
   // sensor
   int B = 0, NB = 0;

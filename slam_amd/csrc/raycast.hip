@@ -7,28 +7,34 @@
 // beta_k = deg_k*pi/180 + theta (never wrapped), then z_k = sqrt(min r2) and the
 // weight prod_k p(z_k | z*_k) * pm.
 //
-// How: the wave visits the 8x8-cell tiles of the obstacle bit plane around the
-// particle nearest-first (a host-built ring table, one tile per lane per pass),
-// compacts the set bits into a per-wave LDS list, and evaluates 64 obstacle
-// cells at a time: exact float64 dx, dy, r2; a float32 bearing selects the
-// beams whose sector the cell can fall into; a cell that is not closer than a
-// beam's current minimum is dropped before any angle test; only where the
-// float32 bearing is within 1e-5 rad of a sector edge is the float64 atan2
-// evaluated.  Each (cell, beam) match is a 64-bit LDS atomic min on the bit
-// pattern of r2 (non-negative doubles order like unsigned integers).  The beam
-// table (sorted angles, bucket index, measured ranges, short-reading constants)
-// and the ring table are staged in LDS once per block.
+// How.  The map is held as per-tile obstacle lists (8x8-cell tiles; tile t owns
+// cells[tile_off[t] .. tile_off[t+1]), each entry (row << 16 | col)).  The wave
+// visits the tiles around the particle nearest-first (a host-built ring table,
+// two tiles per lane per pass), prefix-sums their list lengths across the lanes
+// and then walks the concatenated lists 64 cells at a time: lane j of a batch
+// finds its tile by a binary search over the prefix sums in LDS and loads its
+// cell.  Per cell: exact float64 dx, dy, r2; a float32 bearing selects the beams
+// whose sector the cell can fall into (eight beams per step, all their LDS reads
+// issued together); a cell that is not closer than a beam's current minimum is
+// dropped before any angle test; only where the float32 bearing is within
+// 1e-5 rad of a sector edge is the float64 atan2 evaluated.  Each (cell, beam)
+// match is a 64-bit LDS atomic min on the bit pattern of r2 (non-negative
+// doubles order like unsigned integers).  The beam table (sorted angles, bucket
+// index, measured ranges, short-reading constants) and the ring table are
+// staged in LDS once per block.
 //
 // Compiled with -ffp-contract=off.
+#include <cstdlib>
+
 #include "mclhip_internal.h"
 
 namespace mcl {
 
-constexpr int kListCap = 256;       // per-wave obstacle list; drained in batches of 64 before it can overflow
 constexpr double kEdgeEps = 1e-5;   // float32 bearing is trusted farther than this from a sector edge
 constexpr double kTwoPi = 6.283185307179586;  // == np.pi*2.0
 constexpr int kWavesPerBlock = 4;
 constexpr int kGroup = 8;           // beams examined per step of the matching loop
+constexpr int kWaveScratch = 4 * 64;  // u32 words of per-wave LDS scratch for the tile walk
 
 // ---- cross-lane helpers on the DPP path (no LDS round trip) ----------------
 #define MCL_DPP_I32(old, v, ctrl, rmask) __builtin_amdgcn_update_dpp((old), (v), (ctrl), (rmask), 0xf, false)
@@ -68,11 +74,10 @@ __device__ inline double wave_sum(double v) {
 #define MCL_RAY_WAVES 3
 #endif
 template <typename T, bool STAGE, bool PRODUCT>
-__global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(RayParams P, const T* __restrict__ xs, const T* __restrict__ ys,
-                                                      const T* __restrict__ ths, const uint8_t* __restrict__ pm,
-                                                      int64_t n, double* __restrict__ w_out,
-                                                      double* __restrict__ logw_out, double* __restrict__ ranges_out,
-                                                      int32_t* __restrict__ hits_out) {
+__global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
+    RayParams P, const T* __restrict__ xs, const T* __restrict__ ys, const T* __restrict__ ths,
+    const uint8_t* __restrict__ pm, int64_t n, double* __restrict__ w_out, double* __restrict__ logw_out,
+    double* __restrict__ ranges_out, int32_t* __restrict__ hits_out) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int B = P.B, NB = P.NB;
   // block-wide tables
@@ -81,8 +86,8 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(RayParams P
   double* s_el = s_zt + B;                                        // [B] eta*lambda, sorted order
   unsigned long long* s_rmin_all = reinterpret_cast<unsigned long long*>(s_el + B);
   unsigned long long* s_aux_all = s_rmin_all + (size_t)kWavesPerBlock * B;
-  unsigned int* s_list_all = reinterpret_cast<unsigned int*>(s_aux_all + (size_t)((STAGE || PRODUCT) ? kWavesPerBlock * B : 0));
-  float* s_relf = reinterpret_cast<float*>(s_list_all + (size_t)kWavesPerBlock * kListCap);  // [B] float32(sorted angle - smallest)
+  unsigned int* s_walk_all = reinterpret_cast<unsigned int*>(s_aux_all + (size_t)((STAGE || PRODUCT) ? kWavesPerBlock * B : 0));
+  float* s_relf = reinterpret_cast<float*>(s_walk_all + (size_t)kWavesPerBlock * kWaveScratch);  // [B] float32(angle - smallest)
   unsigned short* s_perm = reinterpret_cast<unsigned short*>(s_relf + B);
   unsigned short* s_lut = s_perm + B;
   unsigned short* s_ring = s_lut + NB;                            // [n_ring] (dty+128) << 8 | (dtx+128)
@@ -104,7 +109,10 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(RayParams P
   const int wv = threadIdx.x >> 6;
   unsigned long long* const rmin = s_rmin_all + (size_t)wv * B;   // per sorted beam: bits of the smallest r2
   unsigned long long* const aux = s_aux_all + (size_t)wv * B;     // STAGE: hit cell; PRODUCT: p_k in caller order
-  unsigned int* const list = s_list_all + (size_t)wv * kListCap;  // packed (row << 16 | col)
+  unsigned int* const w_incl = s_walk_all + (size_t)wv * kWaveScratch;  // inclusive prefix of list lengths per lane
+  unsigned int* const w_split = w_incl + 64;                      // first slot of the lane's second tile
+  unsigned int* const w_adj_a = w_split + 64;                     // cells[] index minus slot, first tile
+  unsigned int* const w_adj_b = w_adj_a + 64;                     // the same, second tile
 
   const unsigned long long r2max_bits = (unsigned long long)__double_as_longlong(P.r2max);
   const float disk_r = (float)(P.z_max * (1.0 + 1e-5) + 0.02 * (P.res_x < P.res_y ? P.res_x : P.res_y));
@@ -113,178 +121,167 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(RayParams P
   const double span = P.ts_max - P.ts_min;
   const double reach = P.half + 2.0 * kEdgeEps;   // candidate window half-width
   const double inv_two_pi = 1.0 / kTwoPi;
+  const double inv_res_x = 1.0 / P.res_x, inv_res_y = 1.0 / P.res_y;
   const float reachf = (float)reach, inv_bwf = (float)P.inv_bw;
   const float sure_in = (float)(P.half - kEdgeEps), sure_out = (float)(P.half + kEdgeEps);
 
-  for (int64_t p = (int64_t)blockIdx.x * kWavesPerBlock + wv; p < n; p += (int64_t)gridDim.x * kWavesPerBlock) {
-    const double x = (double)xs[p], y = (double)ys[p], th = (double)ths[p];
+  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
+  int64_t p = (int64_t)blockIdx.x * kWavesPerBlock + wv;
+  T nx = (T)0, ny = (T)0, nth = (T)0;
+  if (p < n) { nx = xs[p]; ny = ys[p]; nth = ths[p]; }
+  for (; p < n; p += stride) {
+    const double x = (double)nx, y = (double)ny, th = (double)nth;
+    if (p + stride < n) { nx = xs[p + stride]; ny = ys[p + stride]; nth = ths[p + stride]; }  // next pose in flight
     for (int k = lane; k < B; k += 64) {
       rmin[k] = r2max_bits;
       if (STAGE) aux[k] = 0xffffffffull;
     }
     // tile that holds the particle; poses far outside any map (or NaN) visit no tile
-    const double fxc = x / P.res_x, fyc = y / P.res_y;
+    // (a product instead of a division: an index off by one at an exact tile edge is covered by the
+    // ring table's two cells of slack)
+    const double fxc = x * inv_res_x, fyc = y * inv_res_y;
     const bool pose_ok = (fabs(fxc) < 1.0e6) && (fabs(fyc) < 1.0e6);
     const int tcx = pose_ok ? ((int)floor(fxc)) >> 3 : 0;
     const int tcy = pose_ok ? ((int)floor(fyc)) >> 3 : 0;
     const int nt = (pose_ok && fabs(th) < INFINITY && !(P.dbg & 4)) ? P.n_ring : 0;  // NaN / infinite headings match no beam
     const float xf = (float)x, yf = (float)y;
-    const unsigned int lane_cell = ((unsigned int)(lane >> 3) << 16) | (unsigned int)(lane & 7);
 
-    // (row << 16) | col of the first cell of this lane's tile in the pass starting at ring entry `base`
-    auto tile_origin = [&](int base) -> unsigned int {
-      const int t = base + lane;
-      if (t >= nt) return 0u;
+    // (first index into cells[], list length) of ring entry t; empty outside the map or when no
+    // cell of the tile can be within z_max
+    auto tile_list = [&](int t, unsigned int& off, unsigned int& len) {
+      off = 0u;
+      len = 0u;
+      if (t >= nt) return;
       const unsigned int rg = s_ring[t];
       const int ty = tcy + (int)(rg >> 8) - 128, tx = tcx + (int)(rg & 0xffu) - 128;
-      return ((unsigned int)(ty * 8) << 16) | ((unsigned int)(tx * 8) & 0xffffu);
-    };
-    // obstacle bits of that tile; 0 outside the map or when no cell of the tile can be in range
-    auto load_tile = [&](int base) -> unsigned long long {
-      const int t = base + lane;
-      if (t >= nt) return 0ull;
-      const unsigned int rg = s_ring[t];
-      const int ty = tcy + (int)(rg >> 8) - 128, tx = tcx + (int)(rg & 0xffu) - 128;
-      if (ty < 0 || ty >= P.TH || tx < 0 || tx >= P.TW) return 0ull;
+      if (ty < 0 || ty >= P.TH || tx < 0 || tx >= P.TW) return;
       // nearest point of the tile's cell-centre rectangle to the particle
       const float cx0 = (float)(tx * 8) * P.res_xf, cx1 = (float)(tx * 8 + 7) * P.res_xf;
       const float cy0 = (float)(ty * 8) * P.res_yf, cy1 = (float)(ty * 8 + 7) * P.res_yf;
       const float ddx = xf < cx0 ? cx0 - xf : (xf > cx1 ? xf - cx1 : 0.0f);
       const float ddy = yf < cy0 ? cy0 - yf : (yf > cy1 ? yf - cy1 : 0.0f);
-      if (ddx * ddx + ddy * ddy > disk_r2) return 0ull;
-      return P.obst[(size_t)ty * P.TW + tx];
+      if (ddx * ddx + ddy * ddy > disk_r2) return;
+      const unsigned int* to = P.tile_off + ((size_t)ty * P.TW + tx);
+      off = to[0];
+      len = to[1] - off;
+    };
+
+    // one cell against the beam table
+    auto match_cell = [&](unsigned int e, bool valid, int phase) {
+      const int col = (int)(e & 0xffffu), row = (int)(e >> 16);
+      const double ox = (double)((float)col * P.res_xf);  // mc_localization.py:68-71: float32 products
+      const double oy = (double)((float)row * P.res_yf);
+      const double dx = ox - x, dy = oy - y;              // :124-125, float64
+      const double r2 = dx * dx + dy * dy;                // :126
+      if (valid && r2 <= P.r2max && !(P.dbg & 1)) {       // :127
+        float af = (P.dbg & 8) ? (float)dy : atan2f((float)dy, (float)dx);
+        if (af < 0.0f) af += 6.2831855f;
+        const double aa = (double)af;
+        const unsigned long long r2bits = (unsigned long long)__double_as_longlong(r2);
+        const unsigned long long cellbits = (unsigned long long)((unsigned int)row * (unsigned int)P.W + (unsigned int)col);
+        // beams whose table angle lies within `reach` of aa - th + c*2pi, c in {-1, 0, 1}
+        const double psi = (aa - th) - P.ts_min;
+        int c_lo = (int)ceil((-reach - psi) * inv_two_pi);
+        int c_hi = (int)floor((span + reach - psi) * inv_two_pi);
+        c_lo = c_lo < -1 ? -1 : c_lo;
+        c_hi = c_hi > 1 ? 1 : c_hi;
+        double a_exact = 0.0;
+        bool have_exact = false;
+#pragma unroll 1
+        for (int c = c_lo; c <= c_hi; ++c) {
+          // window centre relative to the smallest table angle; small whenever the window can
+          // hold a beam, so float32 is enough for everything but the edge cases
+          const float centref = (float)(psi + (double)c * kTwoPi);
+          const float lof = centref - reachf;
+          int k0 = 0;
+          if (lof > 0.0f) {
+            int bkt = (int)(lof * inv_bwf) - 1;
+            bkt = bkt < 0 ? 0 : (bkt > NB - 1 ? NB - 1 : bkt);
+            k0 = s_lut[bkt];
+          }
+          // beams are visited eight at a time: all sixteen LDS reads of a group are issued
+          // before the first use, so their latency is paid once per group, not once per beam
+#pragma unroll 1
+          for (int kb = k0; kb < B; kb += kGroup) {
+            float eo[kGroup];
+            unsigned long long rm[kGroup];
+#pragma unroll
+            for (int j = 0; j < kGroup; ++j) {
+              const int kk = (kb + j < B) ? kb + j : B - 1;
+              eo[j] = s_relf[kk] - centref;                 // bearing offset from the beam's axis
+              rm[j] = rmin[kk];
+            }
+            unsigned int edge_mask = 0u;
+            bool beyond = false;
+#pragma unroll
+            for (int j = 0; j < kGroup; ++j) {
+              const float ae = fabsf(eo[j]);
+              const bool live = (kb + j < B) && ((STAGE && phase == 1) ? (rm[j] == r2bits) : (r2bits < rm[j]));
+              beyond = beyond || (eo[j] > reachf);
+              if (live && ae <= sure_in) {
+                if (!STAGE || phase == 0) atomicMin(&rmin[kb + j], r2bits);
+                else atomicMin(&aux[kb + j], cellbits);     // lowest row-major index among equally near cells
+              } else if (live && ae < sure_out) {
+                edge_mask |= 1u << j;                       // too close to a sector edge for float32
+              }
+            }
+            while (edge_mask) {                             // rare: exact float64 bearing
+              const int j = __ffs((int)edge_mask) - 1;
+              edge_mask &= edge_mask - 1u;
+              if (!have_exact) {
+                a_exact = atan2(dy, dx);                    // :133
+                if (a_exact < 0.0) a_exact += kTwoPi;       // :134-135
+                have_exact = true;
+              }
+              const double beta = s_ts[kb + j] + th;        // :143
+              const double de = fabs(beta - a_exact);       // :148
+              if ((de <= P.half) || (de >= P.two_pi_lo && de <= P.two_pi_hi)) {  // :149
+                if (!STAGE || phase == 0) atomicMin(&rmin[kb + j], r2bits);
+                else atomicMin(&aux[kb + j], cellbits);
+              }
+            }
+            if (beyond) break;
+          }
+        }
+      }
     };
 
     for (int phase = 0; phase < (STAGE ? 2 : 1); ++phase) {
-      int count = 0;  // wave-uniform number of list entries
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-
-      // evaluates whole batches of 64 list entries (all entries when final)
-      auto drain = [&](bool final_pass) {
+      for (int base = 0; base < nt; base += 128) {
+        // two ring entries per lane, nearest first
+        unsigned int off_a, len_a, off_b, len_b;
+        tile_list(base + 2 * lane, off_a, len_a);
+        tile_list(base + 2 * lane + 1, off_b, len_b);
+        const int incl = wave_incl_scan((int)(len_a + len_b));
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        const unsigned int excl = (unsigned int)incl - (len_a + len_b);
+        w_incl[lane] = (unsigned int)incl;
+        w_split[lane] = excl + len_a;
+        w_adj_a[lane] = off_a - excl;
+        w_adj_b[lane] = off_b - (excl + len_a);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        int b = 0;
-        while (final_pass ? (b < count) : (b + 64 <= count)) {
-          const bool valid = (b + lane) < count;
-          unsigned int e = valid ? list[b + lane] : 0u;
-          const int col = (int)(e & 0xffffu), row = (int)(e >> 16);
-          const double ox = (double)((float)col * P.res_xf);  // mc_localization.py:68-71: float32 products
-          const double oy = (double)((float)row * P.res_yf);
-          const double dx = ox - x, dy = oy - y;              // :124-125, float64
-          const double r2 = dx * dx + dy * dy;                // :126
-          if (valid && r2 <= P.r2max && !(P.dbg & 1)) {                       // :127
-            float af = (P.dbg & 8) ? (float)dy : atan2f((float)dy, (float)dx);
-            if (af < 0.0f) af += 6.2831855f;
-            const double aa = (double)af;
-            const unsigned long long r2bits = (unsigned long long)__double_as_longlong(r2);
-            const unsigned long long cellbits = (unsigned long long)((unsigned int)row * (unsigned int)P.W + (unsigned int)col);
-            // beams whose table angle lies within `reach` of aa - th + c*2pi, c in {-1, 0, 1}
-            const double psi = (aa - th) - P.ts_min;
-            int c_lo = (int)ceil((-reach - psi) * inv_two_pi);
-            int c_hi = (int)floor((span + reach - psi) * inv_two_pi);
-            c_lo = c_lo < -1 ? -1 : c_lo;
-            c_hi = c_hi > 1 ? 1 : c_hi;
-            double a_exact = 0.0;
-            bool have_exact = false;
-#pragma unroll 1
-            for (int c = c_lo; c <= c_hi; ++c) {
-              // window centre relative to the smallest table angle; small whenever the window can
-              // hold a beam, so float32 is enough for everything but the edge cases
-              const float centref = (float)(psi + (double)c * kTwoPi);
-              const float lof = centref - reachf;
-              int k0 = 0;
-              if (lof > 0.0f) {
-                int bkt = (int)(lof * inv_bwf) - 1;
-                bkt = bkt < 0 ? 0 : (bkt > NB - 1 ? NB - 1 : bkt);
-                k0 = s_lut[bkt];
-              }
-              // beams are visited eight at a time: all sixteen LDS reads of a group are issued
-              // before the first use, so their latency is paid once per group, not once per beam
-#pragma unroll 1
-              for (int kb = k0; kb < B; kb += kGroup) {
-                float e[kGroup];
-                unsigned long long rm[kGroup];
+
+        // slot s of the concatenated lists belongs to the first lane whose inclusive prefix exceeds s
+        auto fetch = [&](int sb) -> unsigned int {
+          const unsigned int s = (unsigned int)(sb + lane);
+          if ((int)s >= total) return 0u;
+          int u = 0;
 #pragma unroll
-                for (int j = 0; j < kGroup; ++j) {
-                  const int kk = (kb + j < B) ? kb + j : B - 1;
-                  e[j] = s_relf[kk] - centref;                  // bearing offset from the beam's axis
-                  rm[j] = rmin[kk];
-                }
-                unsigned int edge_mask = 0u;
-                bool beyond = false;
-#pragma unroll
-                for (int j = 0; j < kGroup; ++j) {
-                  const float ae = fabsf(e[j]);
-                  const bool live = (kb + j < B) && ((STAGE && phase == 1) ? (rm[j] == r2bits) : (r2bits < rm[j]));
-                  beyond = beyond || (e[j] > reachf);
-                  if (live && ae <= sure_in) {
-                    if (!STAGE || phase == 0) atomicMin(&rmin[kb + j], r2bits);
-                    else atomicMin(&aux[kb + j], cellbits);     // lowest row-major index among equally near cells
-                  } else if (live && ae < sure_out) {
-                    edge_mask |= 1u << j;                       // too close to a sector edge for float32
-                  }
-                }
-                while (edge_mask) {                             // rare: exact float64 bearing
-                  const int j = __ffs((int)edge_mask) - 1;
-                  edge_mask &= edge_mask - 1u;
-                  if (!have_exact) {
-                    a_exact = atan2(dy, dx);                    // :133
-                    if (a_exact < 0.0) a_exact += kTwoPi;       // :134-135
-                    have_exact = true;
-                  }
-                  const double beta = s_ts[kb + j] + th;        // :143
-                  const double de = fabs(beta - a_exact);       // :148
-                  if ((de <= P.half) || (de >= P.two_pi_lo && de <= P.two_pi_hi)) {  // :149
-                    if (!STAGE || phase == 0) atomicMin(&rmin[kb + j], r2bits);
-                    else atomicMin(&aux[kb + j], cellbits);
-                  }
-                }
-                if (beyond) break;
-              }
-            }
-          }
-          b += 64;
-        }
-        // carry the incomplete batch to the front of the list
-        const int rem = count - b;
-        if (rem > 0) {
-          unsigned int e = (lane < rem) ? list[b + lane] : 0u;
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          if (lane < rem) list[lane] = e;
-          count = rem;
-        } else {
-          count = 0;
+          for (int step = 32; step >= 1; step >>= 1)
+            if (w_incl[u + step - 1] <= s) u += step;
+          const unsigned int idx = (s < w_split[u]) ? w_adj_a[u] + s : w_adj_b[u] + s;
+          return P.cells[idx];
+        };
+
+        unsigned int e_next = fetch(0);
+        for (int sb = 0; sb < total; sb += 64) {
+          const unsigned int e = e_next;
+          if (sb + 64 < total) e_next = fetch(sb + 64);     // next batch in flight while this one is matched
+          match_cell(e, sb + lane < total, phase);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      };
-
-      // Tiles nearest-first, 64 per pass (one per lane).  The non-empty ones are then expanded one
-      // tile at a time with lane = cell of the tile: a cell is kept when its bit is set and a
-      // float32 distance test (a little generous; the exact test follows in drain) puts it within
-      // z_max, and the kept cells are appended to the list in lane order.
-      unsigned long long bits_next = load_tile(0);
-      for (int base = 0; base < nt; base += 64) {
-        const unsigned long long bits = bits_next;
-        const unsigned int my_origin = tile_origin(base);
-        if (base + 64 < nt) bits_next = load_tile(base + 64);   // in flight while this pass is expanded
-        unsigned long long nz = __ballot(bits != 0ull);
-        while (nz != 0ull) {
-          const int src = __ffsll((long long)nz) - 1;
-          nz &= nz - 1ull;
-          const unsigned int tlo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)bits, src);
-          const unsigned int thi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(bits >> 32), src);
-          const unsigned int org = (unsigned int)__builtin_amdgcn_readlane((int)my_origin, src);
-          const unsigned int word = lane < 32 ? tlo : thi;
-          const unsigned int entry = org + lane_cell;            // (row << 16) | col of this lane's cell
-          const float cdx = (float)(entry & 0xffffu) * P.res_xf - xf;
-          const float cdy = (float)(entry >> 16) * P.res_yf - yf;
-          const bool keep = ((word >> (lane & 31)) & 1u) && (cdx * cdx + cdy * cdy <= disk_r2);
-          const unsigned long long km = __ballot(keep);
-          if (keep) list[count + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)km, 0u))] = entry;
-          count += __popcll(km);
-          if (count + 64 > kListCap) drain(false);
-        }
       }
-      drain(true);
     }
 
     // ranges -> beam mixture -> weight
@@ -354,9 +351,9 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(RayParams P
 static size_t ray_lds_bytes(int B, int NB, int n_ring, bool aux) {
   size_t s = (size_t)3 * B * sizeof(double);
   s += (size_t)kWavesPerBlock * B * sizeof(unsigned long long) * (aux ? 2 : 1);
-  s += (size_t)kWavesPerBlock * kListCap * sizeof(unsigned int);
-  s += ((size_t)B + NB + n_ring + 2) * sizeof(unsigned short);
+  s += (size_t)kWavesPerBlock * kWaveScratch * sizeof(unsigned int);
   s += (size_t)B * sizeof(float);
+  s += ((size_t)B + NB + n_ring + 2) * sizeof(unsigned short);
   return (s + 15) & ~(size_t)15;
 }
 
@@ -369,7 +366,7 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
   const size_t lds = ray_lds_bytes(P.B, P.NB, P.n_ring, stage || product);
   if (lds > 64 * 1024) return fail(c, MCLHIP_E_LIMIT, "beam table does not fit the kernel's LDS budget");
   int64_t blocks = (n + kWavesPerBlock - 1) / kWavesPerBlock;
-  const int64_t max_blocks = 256 * 8 * 4;  // a few waves per SIMD; each wave loops over particles
+  static const int64_t max_blocks = getenv("MCLHIP_RAY_BLOCKS") ? atoll(getenv("MCLHIP_RAY_BLOCKS")) : 256 * 8 * 4;  // each wave loops over particles
   if (blocks > max_blocks) blocks = max_blocks;
   dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
   if (stage) {
