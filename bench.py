@@ -68,6 +68,24 @@ def cpu_baseline(grid, angles, X, z_meas, ut, n_particles):
                       "cost is linear in the particle count" % (n_particles, len(angles), len(orc.lut), dt)}
 
 
+def profiled_traffic(args):
+    """HBM bytes per launch of the sector-query kernel from the committed rocprofv3 counter passes
+    (profiles/rNN_pmc_per_kernel.json; FETCH_SIZE and WRITE_SIZE are in KiB, collected in separate
+    passes; FETCH_SIZE doubled as gfx950 tallies 128-B requests at 64 B).  Only valid for the
+    default workload the passes were run on; None otherwise."""
+    import glob
+    if (args.particles, args.beams, args.map, args.dtype, args.regime) != (1 << 20, 180, 4096, "f32", "global"):
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_per_kernel.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    for name, ctr in d.items():
+        if "raycast_kernel<float, false, false>" in name and "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
+            return (2.0 * ctr["FETCH_SIZE"]["per_launch_mean"] + ctr["WRITE_SIZE"]["per_launch_mean"]) * 1024.0
+    return None
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -163,7 +181,9 @@ def main():
                        "particles_per_gpu": M, "beams": B, "map": a.map, "regime": a.regime,
                        "sharding": "contiguous particle ranges, map replicated" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": profiled_traffic(a),
+                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, profiles/)",
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_EVAL * float(M) * B,
                          "kernel": "raycast_kernel (sector query + beam likelihood)",
                          "kernel_ms": ray_ms, "launches": n_ray,
                          "algorithmic_bytes_per_eval": ALGO_BYTES_PER_EVAL},

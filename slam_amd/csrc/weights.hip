@@ -95,11 +95,15 @@ __global__ __launch_bounds__(256) void max_partial_kernel(const double* __restri
   if (threadIdx.x == 0) part[blockIdx.x] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
 }
 
-__global__ void max_final_kernel(const double* __restrict__ part, int np, double* __restrict__ scal) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(256) void max_final_kernel(const double* __restrict__ part, int np,
+                                                        double* __restrict__ scal) {
+  __shared__ double sm[4];
   double m = -INFINITY;
-  for (int i = 0; i < np; ++i) m = fmax(m, part[i]);
-  scal[1] = m;
+  for (int i = threadIdx.x; i < np; i += blockDim.x) m = fmax(m, part[i]);
+  for (int d = 32; d >= 1; d >>= 1) m = fmax(m, __shfl_xor(m, d, 64));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) scal[1] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
 }
 
 __global__ void exp_shift_kernel(const double* __restrict__ logw, double* __restrict__ w, int64_t n,
@@ -117,7 +121,7 @@ int launch_normalise(mclhip_ctx* c, int mode) {
   if (mode == MCLHIP_W_LOG) {
     const int np = 1024;
     hipLaunchKernelGGL(max_partial_kernel, dim3(np), dim3(256), 0, c->stream, c->logw, n, (double*)c->blk_a);
-    hipLaunchKernelGGL(max_final_kernel, dim3(1), dim3(64), 0, c->stream, (const double*)c->blk_a, np, c->scal);
+    hipLaunchKernelGGL(max_final_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)c->blk_a, np, c->scal);
     hipLaunchKernelGGL(exp_shift_kernel, dim3(g), dim3(256), 0, c->stream, c->logw, w, n, c->scal);
   }
   const int nchunks = (int)((n + kSumChunk - 1) / kSumChunk);
@@ -452,7 +456,7 @@ __global__ void exp_shift_by_kernel(const double* __restrict__ logw, double* __r
 int launch_shard_max_logw(mclhip_ctx* c) {
   const int np = 1024;
   hipLaunchKernelGGL(max_partial_kernel, dim3(np), dim3(256), 0, c->stream, c->logw, c->M, (double*)c->blk_a);
-  hipLaunchKernelGGL(max_final_kernel, dim3(1), dim3(64), 0, c->stream, (const double*)c->blk_a, np, c->scal);
+  hipLaunchKernelGGL(max_final_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)c->blk_a, np, c->scal);
   MCL_HIP(c, hipGetLastError());
   return MCLHIP_OK;
 }
