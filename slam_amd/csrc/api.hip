@@ -35,6 +35,7 @@ RayParams make_ray_params(const mclhip_ctx* c) {
   P.tab_sorted = c->tab_sorted; P.tab_orig = c->tab_orig; P.perm = c->perm; P.lut = c->lut;
   P.ring = c->ring; P.n_ring = c->n_ring;
   P.ts_min = c->ts_min; P.ts_max = c->ts_max; P.inv_bw = c->inv_bw;
+  P.relx = c->relx; P.G = c->G; P.ext_min = c->ext_min;
   P.half = c->half;
   P.two_pi_lo = M_PI * 2 - c->half;  // mc_localization.py:149
   P.two_pi_hi = M_PI * 2 + c->half;
@@ -242,7 +243,7 @@ void mclhip_destroy(mclhip_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  void* ptrs[] = {c->obst, c->freeb, c->tile_off, c->cells, c->tab_sorted, c->tab_orig, c->perm, c->lut, c->zt, c->etalam, c->zmeas_stage, c->ring,
+  void* ptrs[] = {c->obst, c->freeb, c->tile_off, c->cells, c->tab_sorted, c->tab_orig, c->perm, c->lut, c->relx, c->zt, c->etalam, c->zmeas_stage, c->ring,
                   c->px[0], c->px[1], c->py[0], c->py[1], c->pth[0], c->pth[1], c->w[0], c->w[1], c->logw, c->pm,
                   c->sx, c->sy, c->sth, c->sw, c->chunk_sums, c->scal, c->cdf_approx, c->cdf_exact, c->kscan,
                   c->fscan, c->blk_a, c->blk_b, c->irr, c->bases, c->idx, c->noise, c->counters, c->g_records, c->g_bases,
@@ -317,18 +318,35 @@ int mclhip_set_sensor(mclhip_ctx* c, const double* angles_deg, int B, double z_m
   std::iota(perm.begin(), perm.end(), 0);
   std::stable_sort(perm.begin(), perm.end(), [&](uint16_t a, uint16_t b) { return tab[a] < tab[b]; });
   for (int k = 0; k < B; ++k) ts[k] = tab[perm[k]];
-  int NB = 1;
-  while (NB < 2 * B) NB <<= 1;
-  c->NB = NB;
   c->ts_min = ts.front(); c->ts_max = ts.back();
   const double span = c->ts_max - c->ts_min;
-  const double bw = span / NB;
-  c->inv_bw = (span > 0) ? 1.0 / bw : 0.0;
+  // Extended table for the sector query: beams within two window half-widths of one turn above the
+  // smallest angle also appear one turn lower, so that a window that straddles the 0 / 2pi seam of
+  // the bearing is one contiguous run of entries.
+  const double reach = half + 2.0 * kEdgeEps;
+  const double two_pi = M_PI * 2;
+  std::vector<float> relx;
+  int G = 0;
+  for (int k = 0; k < B; ++k)
+    if (ts[k] - c->ts_min >= two_pi - 2.0 * reach - 1e-6) ++G;
+  if (G > B - 1) G = B > 1 ? B - 1 : 0;   // never an image of every beam
+  for (int k = B - G; k < B; ++k) relx.push_back((float)((ts[k] - c->ts_min) - two_pi));
+  for (int k = 0; k < B; ++k) relx.push_back((float)(ts[k] - c->ts_min));
+  c->G = G;
+  c->ext_min = (double)relx.front();
+  int NB = 1;
+  while (NB < 2 * (B + G)) NB <<= 1;
+  c->NB = NB;
+  const double ext_span = span - c->ext_min;
+  const double bw = ext_span / NB;
+  c->inv_bw = (ext_span > 0) ? 1.0 / bw : 0.0;
   std::vector<uint16_t> lut(NB);
   for (int b = 0; b < NB; ++b) {
-    const double edge = c->ts_min + b * bw;
-    lut[b] = (uint16_t)(std::lower_bound(ts.begin(), ts.end(), edge) - ts.begin());
+    const float edge = (float)(c->ext_min + b * bw);
+    lut[b] = (uint16_t)(std::lower_bound(relx.begin(), relx.end(), edge) - relx.begin());
   }
+  MCL_TRY(dev_alloc(c, &c->relx, relx.size() * sizeof(float)));
+  MCL_HIP(c, hipMemcpy(c->relx, relx.data(), relx.size() * sizeof(float), hipMemcpyHostToDevice));
   MCL_TRY(dev_alloc(c, &c->tab_sorted, B * sizeof(double)));
   MCL_TRY(dev_alloc(c, &c->tab_orig, B * sizeof(double)));
   MCL_TRY(dev_alloc(c, &c->perm, B * sizeof(uint16_t)));

@@ -14,6 +14,7 @@ namespace mcl {
 
 constexpr int kWave = 64;
 constexpr int kMaxBeams = 1024;
+constexpr double kEdgeEps = 1e-5;  // the float32 bearing of the sector query is trusted farther than this from a sector edge
 constexpr int kSumChunk = 8192;   // numpy reduces float64 vectors chunk by chunk of this size
 constexpr int kScanBlock = 256;   // threads per scan block
 constexpr int kScanItems = 8;     // elements per thread in the scans
@@ -31,7 +32,11 @@ struct RayParams {
   const double* tab_sorted;  // beam angles in radians (deg*pi/180), ascending
   const double* tab_orig;    // the same, in the caller's beam order
   const uint16_t* perm;      // sorted position -> caller's beam index
-  const uint16_t* lut;       // bucket -> first sorted position at or after the bucket's lower edge
+  const uint16_t* lut;       // bucket -> first position of the extended table at or after the bucket's lower edge
+  const float* relx;         // [G + B] extended table: float32(angle - smallest angle); the first G entries are
+                             // the last G beams moved down one turn (their images across the 0 / 2pi seam)
+  int G;                     // number of such images
+  double ext_min;            // relx[0] as float64 (<= 0): lower end of the bucket index
   const uint16_t* ring;      // tile offsets around the particle's tile, nearest first: (dty+128) << 8 | (dtx+128)
   int n_ring;
   double ts_min, ts_max, inv_bw;
@@ -83,6 +88,9 @@ struct mclhip_ctx {
   double* tab_orig = nullptr;
   uint16_t* perm = nullptr;
   uint16_t* lut = nullptr;
+  float* relx = nullptr;
+  int G = 0;
+  double ext_min = 0;
   double* zt = nullptr;      // [B]
   double* etalam = nullptr;  // [B]
   double* zmeas_stage = nullptr;  // [B] staging for z_meas uploads

@@ -30,7 +30,6 @@
 
 namespace mcl {
 
-constexpr double kEdgeEps = 1e-5;   // float32 bearing is trusted farther than this from a sector edge
 constexpr double kTwoPi = 6.283185307179586;  // == np.pi*2.0
 constexpr int kWavesPerBlock = 4;
 constexpr int kGroup = 8;           // beams examined per step of the matching loop
@@ -87,20 +86,20 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
   unsigned long long* s_rmin_all = reinterpret_cast<unsigned long long*>(s_el + B);
   unsigned long long* s_aux_all = s_rmin_all + (size_t)kWavesPerBlock * B;
   unsigned int* s_walk_all = reinterpret_cast<unsigned int*>(s_aux_all + (size_t)((STAGE || PRODUCT) ? kWavesPerBlock * B : 0));
-  float* s_relf = reinterpret_cast<float*>(s_walk_all + (size_t)kWavesPerBlock * kWaveScratch);  // [B] float32(angle - smallest)
-  unsigned short* s_perm = reinterpret_cast<unsigned short*>(s_relf + B);
+  float* s_relx = reinterpret_cast<float*>(s_walk_all + (size_t)kWavesPerBlock * kWaveScratch);  // [G + B] extended angle table
+  unsigned short* s_perm = reinterpret_cast<unsigned short*>(s_relx + (P.G + B));
   unsigned short* s_lut = s_perm + B;
   unsigned short* s_ring = s_lut + NB;                            // [n_ring] (dty+128) << 8 | (dtx+128)
 
   for (int k = threadIdx.x; k < B; k += blockDim.x) {
     s_ts[k] = P.tab_sorted[k];
-    s_relf[k] = (float)(P.tab_sorted[k] - P.ts_min);
     s_perm[k] = P.perm[k];
     if (!STAGE) {
       s_zt[k] = P.zt[k];
       s_el[k] = P.etalam[k];
     }
   }
+  for (int k = threadIdx.x; k < P.G + B; k += blockDim.x) s_relx[k] = P.relx[k];
   for (int k = threadIdx.x; k < NB; k += blockDim.x) s_lut[k] = P.lut[k];
   for (int k = threadIdx.x; k < P.n_ring; k += blockDim.x) s_ring[k] = P.ring[k];
   __syncthreads();
@@ -122,7 +121,9 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
   const double reach = P.half + 2.0 * kEdgeEps;   // candidate window half-width
   const double inv_two_pi = 1.0 / kTwoPi;
   const double inv_res_x = 1.0 / P.res_x, inv_res_y = 1.0 / P.res_y;
-  const float reachf = (float)reach, inv_bwf = (float)P.inv_bw;
+  const float reachf = (float)reach, inv_bwf = (float)P.inv_bw, ext_minf = (float)P.ext_min;
+  const int G = P.G, NX = P.G + B;
+  const bool seam = span < kTwoPi - 1e-9;   // images of the top beams exist: one window covers both sides of the seam
   const float sure_in = (float)(P.half - kEdgeEps), sure_out = (float)(P.half + kEdgeEps);
 
   const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
@@ -187,40 +188,45 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
         c_hi = c_hi > 1 ? 1 : c_hi;
         double a_exact = 0.0;
         bool have_exact = false;
+        // With the seam images in the table every lane needs one pass (its lowest window; the next
+        // window's beams appear as images inside it), so the lanes of a batch stay together.
 #pragma unroll 1
-        for (int c = c_lo; c <= c_hi; ++c) {
+        for (int c = c_lo; c <= c_hi; c += (seam ? 2 : 1)) {
           // window centre relative to the smallest table angle; small whenever the window can
           // hold a beam, so float32 is enough for everything but the edge cases
           const float centref = (float)(psi + (double)c * kTwoPi);
           const float lof = centref - reachf;
-          int k0 = 0;
-          if (lof > 0.0f) {
-            int bkt = (int)(lof * inv_bwf) - 1;
+          int i0 = 0;
+          if (lof > ext_minf) {
+            int bkt = (int)((lof - ext_minf) * inv_bwf) - 1;
             bkt = bkt < 0 ? 0 : (bkt > NB - 1 ? NB - 1 : bkt);
-            k0 = s_lut[bkt];
+            i0 = s_lut[bkt];
           }
+          if (!(seam && c + 1 <= c_hi) && i0 < G) i0 = G;   // images stand for window c + 1: skip them if it is not allowed
           // beams are visited eight at a time: all sixteen LDS reads of a group are issued
           // before the first use, so their latency is paid once per group, not once per beam
 #pragma unroll 1
-          for (int kb = k0; kb < B; kb += kGroup) {
+          for (int kb = i0; kb < ((P.dbg & 64) ? 0 : NX); kb += kGroup) {
             float eo[kGroup];
             unsigned long long rm[kGroup];
+            int kx[kGroup];
 #pragma unroll
             for (int j = 0; j < kGroup; ++j) {
-              const int kk = (kb + j < B) ? kb + j : B - 1;
-              eo[j] = s_relf[kk] - centref;                 // bearing offset from the beam's axis
-              rm[j] = rmin[kk];
+              const int ii = (kb + j < NX) ? kb + j : NX - 1;
+              eo[j] = s_relx[ii] - centref;                 // bearing offset from the beam's axis
+              kx[j] = ii - G + (ii < G ? B : 0);            // sorted beam index of this table entry
+              rm[j] = rmin[kx[j]];
             }
             unsigned int edge_mask = 0u;
             bool beyond = false;
 #pragma unroll
             for (int j = 0; j < kGroup; ++j) {
               const float ae = fabsf(eo[j]);
-              const bool live = (kb + j < B) && ((STAGE && phase == 1) ? (rm[j] == r2bits) : (r2bits < rm[j]));
+              const bool live = (kb + j < NX) && ((STAGE && phase == 1) ? (rm[j] == r2bits) : (r2bits < rm[j]));
               beyond = beyond || (eo[j] > reachf);
-              if (live && ae <= sure_in) {
-                if (!STAGE || phase == 0) atomicMin(&rmin[kb + j], r2bits);
-                else atomicMin(&aux[kb + j], cellbits);     // lowest row-major index among equally near cells
+              if (live && ae <= sure_in && !(P.dbg & 32)) {
+                if (!STAGE || phase == 0) atomicMin(&rmin[kx[j]], r2bits);
+                else atomicMin(&aux[kx[j]], cellbits);     // lowest row-major index among equally near cells
               } else if (live && ae < sure_out) {
                 edge_mask |= 1u << j;                       // too close to a sector edge for float32
               }
@@ -233,11 +239,13 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
                 if (a_exact < 0.0) a_exact += kTwoPi;       // :134-135
                 have_exact = true;
               }
-              const double beta = s_ts[kb + j] + th;        // :143
+              const int ie = kb + j;
+              const int ke = ie - G + (ie < G ? B : 0);
+              const double beta = s_ts[ke] + th;            // :143
               const double de = fabs(beta - a_exact);       // :148
               if ((de <= P.half) || (de >= P.two_pi_lo && de <= P.two_pi_hi)) {  // :149
-                if (!STAGE || phase == 0) atomicMin(&rmin[kb + j], r2bits);
-                else atomicMin(&aux[kb + j], cellbits);
+                if (!STAGE || phase == 0) atomicMin(&rmin[ke], r2bits);
+                else atomicMin(&aux[ke], cellbits);
               }
             }
             if (beyond) break;
@@ -348,11 +356,11 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
   }
 }
 
-static size_t ray_lds_bytes(int B, int NB, int n_ring, bool aux) {
+static size_t ray_lds_bytes(int B, int G, int NB, int n_ring, bool aux) {
   size_t s = (size_t)3 * B * sizeof(double);
   s += (size_t)kWavesPerBlock * B * sizeof(unsigned long long) * (aux ? 2 : 1);
   s += (size_t)kWavesPerBlock * kWaveScratch * sizeof(unsigned int);
-  s += (size_t)B * sizeof(float);
+  s += (size_t)(B + G) * sizeof(float);
   s += ((size_t)B + NB + n_ring + 2) * sizeof(unsigned short);
   return (s + 15) & ~(size_t)15;
 }
@@ -363,7 +371,7 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
   if (n <= 0) return MCLHIP_OK;
   RayParams P = make_ray_params(c);
   const bool stage = ranges_out != nullptr;
-  const size_t lds = ray_lds_bytes(P.B, P.NB, P.n_ring, stage || product);
+  const size_t lds = ray_lds_bytes(P.B, P.G, P.NB, P.n_ring, stage || product);
   if (lds > 64 * 1024) return fail(c, MCLHIP_E_LIMIT, "beam table does not fit the kernel's LDS budget");
   int64_t blocks = (n + kWavesPerBlock - 1) / kWavesPerBlock;
   static const int64_t max_blocks = getenv("MCLHIP_RAY_BLOCKS") ? atoll(getenv("MCLHIP_RAY_BLOCKS")) : 256 * 8 * 4;  // each wave loops over particles
