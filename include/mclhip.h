@@ -144,6 +144,25 @@ int mclhip_step_async(mclhip_ctx* ctx, double v, double omega, double dt, const 
                       uint64_t seed, const double* z_meas, int weight_mode, double r);
 int mclhip_sync(mclhip_ctx* ctx);
 
+/* Augmented MCL (mc_localization2.py, Table 8.3) -----------------------------
+ * Replaces the particle loop of its sample() (mc_localization2.py:231-246): as
+ * mclhip_sample, plus range_noise [M][B] (caller beam order, nullable): the
+ * term randn()*0.15 added to every predicted range (:166-168), and the running
+ * mean w_avg = sum_m w[m]/M accumulated strictly left to right (:246), which is
+ * returned in w_avg_out.  noise_ints here come from np.random.randint(-1000,
+ * 1000, 12) (:23). */
+int mclhip_sample_augmented(mclhip_ctx* ctx, double v, double omega, double dt, const double alpha[6],
+                            const int16_t* noise_ints, uint64_t seed, const double* z_meas,
+                            const double* range_noise, double* w_avg_out);
+
+/* Replaces the walk of its resample() (mc_localization2.py:266-296) after
+ * mclhip_normalise: positions inj_rows[j] (ascending) receive the pose
+ * inj_poses[j] and the weight 1/M instead of a resampled particle.  As in the
+ * reference, the injected poses overwrite X in place first, so a position that
+ * resamples source row inj_rows[j] gets the injected pose too. */
+int mclhip_resample_augmented(mclhip_ctx* ctx, double r, const int64_t* inj_rows, const double* inj_poses,
+                              int64_t n_inj, int64_t* idx_out);
+
 /* Re-load the particle set from a device-resident snapshot taken by
  * mclhip_snapshot_particles (benchmark helper: every timed step starts from
  * the same synthetic cloud; a device-to-device copy, no host traffic). */

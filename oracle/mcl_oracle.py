@@ -347,3 +347,55 @@ class OracleMCL:
         self.idx = resample_indices(self.w, r, clamp)
         self.X = self.X[self.idx]
         self.w = self.w[self.idx]
+
+
+# --------------------------------------------------------------------------
+# next row: augmented MCL                 mc_localization2.py (Table 8.3)
+# --------------------------------------------------------------------------
+def amcl_weights(R, range_noise, z_meas, pm, sp, no_obstacles=False):
+    """Weights with noisy predicted ranges: r += randn()*0.15 per beam
+    (mc_localization2.py:166-168); without obstacles the reading is
+    min(z_max, z_max + noise) (:170-173).  Returns (w, P)."""
+    Z = np.minimum(sp.z_max, sp.z_max + range_noise) if no_obstacles else R + range_noise
+    P = beam_px(Z, np.asarray(z_meas)[None, :], sp)
+    q = np.ones(len(Z))
+    for k in range(P.shape[1]):
+        q = q * P[:, k]
+    return q * pm, P
+
+
+def sequential_mean(w):
+    """w_avg of mc_localization2.py:228-246: `w_avg += w[m] / M` from 0, strictly left to right."""
+    w = np.asarray(w, np.float64)
+    return np.float64(np.cumsum(w / len(w))[-1])
+
+
+def amcl_rates(w_slow, w_fast, w_avg, a_slow=0.001, a_fast=0.9):
+    """mc_localization2.py:248-249."""
+    return w_slow + a_slow * (w_avg - w_slow), w_fast + a_fast * (w_avg - w_fast)
+
+
+def amcl_resample(X, w_norm, r, inject_rows, inject_poses, clamp=False):
+    """mc_localization2.py:266-296.  Injected positions get a fresh pose and weight 1/M; the
+    others follow the low-variance walk.  The reference writes the injected poses into self.X
+    in place and collects row *views*, so every position that resamples an injected row ends
+    up with the injected pose as well -- reproduced here."""
+    M = len(w_norm)
+    idx = resample_indices(w_norm, r, clamp=True)
+    inject_rows = np.asarray(inject_rows, np.int64)
+    walk = np.ones(M, bool)
+    walk[inject_rows] = False
+    c = np.cumsum(w_norm)
+    if not clamp and np.any(walk) and not np.isnan(c[-1]):
+        U = r + (np.arange(M) / M)
+        if np.any(U[walk] > c[-1]):
+            raise IndexError("resample walk ran past the last particle")
+    Xmod = np.array(X, np.float64, copy=True)
+    if len(inject_rows):
+        Xmod[inject_rows] = inject_poses
+    Xo = Xmod[idx]
+    wo = np.asarray(w_norm, np.float64)[idx].copy()
+    if len(inject_rows):
+        Xo[inject_rows] = inject_poses
+        wo[inject_rows] = 1.0 / M
+    return Xo, wo, idx

@@ -48,6 +48,9 @@ PROTOTYPES = {
                               C.c_int, C.c_double]),
     "mclhip_step_async": (C.c_int, [_ctx_p, C.c_double, C.c_double, C.c_double, _dbl_p, C.c_uint64, _dbl_p, C.c_int,
                                     C.c_double]),
+    "mclhip_sample_augmented": (C.c_int, [_ctx_p, C.c_double, C.c_double, C.c_double, _dbl_p, _i16_p, C.c_uint64,
+                                          _dbl_p, _dbl_p, _dbl_p]),
+    "mclhip_resample_augmented": (C.c_int, [_ctx_p, C.c_double, _i64_p, _dbl_p, C.c_int64, _i64_p]),
     "mclhip_sync": (C.c_int, [_ctx_p]),
     "mclhip_snapshot_particles": (C.c_int, [_ctx_p]),
     "mclhip_restore_particles_async": (C.c_int, [_ctx_p]),
@@ -212,6 +215,29 @@ class Context:
         nz = self._noise(noise_ints)
         self._ck(self.lib.mclhip_sample(self.h, float(v), float(omega), float(dt), _p(al, _dbl_p), _p(nz, _i16_p),
                                         int(seed), _p(zm, _dbl_p)), "mclhip_sample")
+
+    def sample_augmented(self, v, omega, dt, alpha, z_meas, noise_ints=None, range_noise=None, seed=0):
+        """-> w_avg, the strictly sequential sum of w[m]/M."""
+        al = _f64(alpha, (6,))
+        zm = _f64(z_meas, (self.B,))
+        nz = self._noise(noise_ints)
+        rn = None if range_noise is None else _f64(range_noise, (self.num_particles(), self.B))
+        wavg = C.c_double(0.0)
+        self._ck(self.lib.mclhip_sample_augmented(self.h, float(v), float(omega), float(dt), _p(al, _dbl_p),
+                                                  _p(nz, _i16_p), int(seed), _p(zm, _dbl_p), _p(rn, _dbl_p),
+                                                  C.byref(wavg)), "mclhip_sample_augmented")
+        return wavg.value
+
+    def resample_augmented(self, r, inj_rows, inj_poses, want_idx=True):
+        rows = np.ascontiguousarray(inj_rows, dtype=np.int64).ravel()
+        poses = _f64(inj_poses).reshape(-1, 3)
+        if len(rows) != len(poses):
+            raise ValueError("one pose per injected row")
+        idx = np.empty(self.num_particles(), np.int64) if want_idx else None
+        self._ck(self.lib.mclhip_resample_augmented(self.h, float(r), _p(rows, _i64_p) if len(rows) else None,
+                                                    _p(poses, _dbl_p) if len(rows) else None, len(rows),
+                                                    _p(idx, _i64_p)), "mclhip_resample_augmented")
+        return idx
 
     def normalise(self, mode=W_PRODUCT):
         s = C.c_double(0.0)

@@ -46,6 +46,8 @@ RayParams make_ray_params(const mclhip_ctx* c) {
   P.w_hit = c->w4[0]; P.w_short = c->w4[1]; P.w_max = c->w4[2]; P.w_rand = c->w4[3];
   P.p_rand = 1 / c->z_max;                               // range_sensor.py:64
   { const char* d = getenv("MCLHIP_ABLATE"); P.dbg = d ? atoi(d) : 0; }
+  P.range_noise = nullptr;
+  P.no_obstacles = c->n_obstacles == 0 ? 1 : 0;
   return P;
 }
 
@@ -173,7 +175,8 @@ static int need(mclhip_ctx* c, bool map, bool sensor, bool particles) {
 
 // enqueue motion + sector query + likelihood for the live particle set
 static int enqueue_sample(mclhip_ctx* c, double v, double omega, double dt, const double* alpha, int noise_mode,
-                          uint64_t seed, std::vector<mclhip_ctx::Span>& spans, bool want_product) {
+                          uint64_t seed, std::vector<mclhip_ctx::Span>& spans, bool want_product,
+                          const double* d_range_noise = nullptr) {
   MCL_TRY(launch_beam_table(c));
   MotionParams mp = make_motion_params(c, v, omega, dt, alpha, noise_mode, seed);
   const int a = c->cur;
@@ -183,7 +186,7 @@ static int enqueue_sample(mclhip_ctx* c, double v, double omega, double dt, cons
   span_begin(c, spans, 0);
   // the raw product is only formed when somebody will read it: it costs one dependent multiply per beam
   MCL_TRY(launch_raycast(c, c->px[a], c->py[a], c->pth[a], c->pm, c->M, c->dtype, want_product ? c->w[a] : nullptr,
-                         c->logw, nullptr, nullptr));
+                         c->logw, nullptr, nullptr, d_range_noise));
   span_end(c, spans);
   return MCLHIP_OK;
 }
@@ -246,7 +249,8 @@ void mclhip_destroy(mclhip_ctx* c) {
   void* ptrs[] = {c->obst, c->freeb, c->tile_off, c->cells, c->tab_sorted, c->tab_orig, c->perm, c->lut, c->relx, c->zt, c->etalam, c->zmeas_stage, c->ring,
                   c->px[0], c->px[1], c->py[0], c->py[1], c->pth[0], c->pth[1], c->w[0], c->w[1], c->logw, c->pm,
                   c->sx, c->sy, c->sth, c->sw, c->chunk_sums, c->scal, c->cdf_approx, c->cdf_exact, c->kscan,
-                  c->fscan, c->blk_a, c->blk_b, c->irr, c->bases, c->idx, c->noise, c->counters, c->g_records, c->g_bases,
+                  c->fscan, c->blk_a, c->blk_b, c->irr, c->bases, c->idx, c->noise, c->counters, c->range_noise, c->inj_rows,
+                  c->inj_poses, c->g_records, c->g_bases,
                   c->rows_send, c->rows_recv, c->small_d, c->small_i};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -518,6 +522,55 @@ int mclhip_sample(mclhip_ctx* c, double v, double omega, double dt, const double
   MCL_TRY(enqueue_sample(c, v, omega, dt, alpha, noise_ints ? 1 : 2, seed, spans, true));
   MCL_HIP(c, hipStreamSynchronize(c->stream));
   span_collect(c, spans);
+  return MCLHIP_OK;
+}
+
+int mclhip_sample_augmented(mclhip_ctx* c, double v, double omega, double dt, const double alpha[6],
+                            const int16_t* noise_ints, uint64_t seed, const double* z_meas,
+                            const double* range_noise, double* w_avg_out) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, true, true, true));
+  if (!alpha) return fail(c, MCLHIP_E_ARG, "alpha is NULL");
+  MCL_TRY(upload_zmeas(c, z_meas));
+  if (noise_ints) MCL_TRY(upload_noise(c, noise_ints));
+  if (range_noise) {
+    const size_t bytes = (size_t)c->M * c->B * sizeof(double);
+    MCL_TRY(dev_alloc(c, &c->range_noise, bytes));
+    MCL_HIP(c, hipMemcpyAsync(c->range_noise, range_noise, bytes, hipMemcpyHostToDevice, c->stream));
+  }
+  MCL_TRY(enqueue_sample(c, v, omega, dt, alpha, noise_ints ? 1 : 2, seed, c->spans, true,
+                         range_noise ? c->range_noise : nullptr));
+  MCL_TRY(launch_mean_weight(c));
+  MCL_HIP(c, hipStreamSynchronize(c->stream));
+  span_collect(c, c->spans);
+  if (w_avg_out) MCL_HIP(c, hipMemcpy(w_avg_out, c->scal + 2, sizeof(double), hipMemcpyDeviceToHost));
+  return MCLHIP_OK;
+}
+
+int mclhip_resample_augmented(mclhip_ctx* c, double r, const int64_t* inj_rows, const double* inj_poses,
+                              int64_t n_inj, int64_t* idx_out) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, false, false, true));
+  if (n_inj < 0 || n_inj > c->M || (n_inj && (!inj_rows || !inj_poses)))
+    return fail(c, MCLHIP_E_ARG, "bad injection list");
+  for (int64_t j = 0; j < n_inj; ++j)
+    if (inj_rows[j] < 0 || inj_rows[j] >= c->M) return fail(c, MCLHIP_E_ARG, "injected row outside [0, M)");
+  if (n_inj > c->inj_cap) {
+    MCL_TRY(dev_alloc(c, &c->inj_rows, (size_t)n_inj * sizeof(int64_t)));
+    MCL_TRY(dev_alloc(c, &c->inj_poses, (size_t)n_inj * 3 * sizeof(double)));
+    c->inj_cap = n_inj;
+  }
+  if (n_inj) {
+    MCL_HIP(c, hipMemcpyAsync(c->inj_rows, inj_rows, n_inj * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    MCL_HIP(c, hipMemcpyAsync(c->inj_poses, inj_poses, n_inj * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  }
+  // self.X[m] = (x, y, a) in place, before the walk reads X (mc_localization2.py:284-286)
+  MCL_TRY(launch_inject(c, c->inj_rows, c->inj_poses, n_inj, c->cur, false));
+  MCL_TRY(launch_resample(c, r, MCLHIP_RESAMPLE_PARALLEL));
+  // the injected positions themselves: pose and weight 1/M (:287-288)
+  MCL_TRY(launch_inject(c, c->inj_rows, c->inj_poses, n_inj, c->cur, true));
+  MCL_HIP(c, hipStreamSynchronize(c->stream));
+  if (idx_out) MCL_HIP(c, hipMemcpy(idx_out, c->idx, c->M * sizeof(int64_t), hipMemcpyDeviceToHost));
   return MCLHIP_OK;
 }
 

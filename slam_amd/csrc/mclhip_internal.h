@@ -50,6 +50,8 @@ struct RayParams {
   double w_hit, w_short, w_max, w_rand;
   double p_rand;         // 1/z_max
   int dbg;               // profiling ablations (0 in production)
+  const double* range_noise;  // [n][B] additive noise on the predicted ranges, caller beam order (augmented MCL) or null
+  int no_obstacles;      // the map holds no obstacle cell
 };
 
 struct MotionParams {
@@ -123,6 +125,10 @@ struct mclhip_ctx {
   void* bases = nullptr;         // run bases
   int64_t* idx = nullptr;        // [M]
   int16_t* noise = nullptr;      // [M][3][12] staging for pre-drawn integers
+  double* range_noise = nullptr; // [M][B] staging for the additive range noise of augmented MCL
+  int64_t* inj_rows = nullptr;   // injected-particle staging (augmented MCL)
+  double* inj_poses = nullptr;
+  int64_t inj_cap = 0;
   uint32_t* counters = nullptr;  // small device counters
 
   // multi-GPU: this context's slice of one global particle vector
@@ -159,7 +165,11 @@ int build_ring_table(mclhip_ctx* c);
 int launch_motion(mclhip_ctx* c, void* x, void* y, void* th, uint8_t* pm, int64_t n, const MotionParams& mp,
                   const int16_t* d_noise, int dtype);
 int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, const uint8_t* pm, int64_t n,
-                   int dtype, double* w_out, double* logw_out, double* ranges_out, int32_t* hits_out);
+                   int dtype, double* w_out, double* logw_out, double* ranges_out, int32_t* hits_out,
+                   const double* range_noise = nullptr);
+int launch_mean_weight(mclhip_ctx* c);
+int launch_inject(mclhip_ctx* c, const int64_t* d_rows, const double* d_poses, int64_t n_inj, int which_buffer,
+                  bool set_weight);
 int launch_compute_px(mclhip_ctx* c, const double* z, const double* zt, int64_t n, double* p);
 int launch_normalise(mclhip_ctx* c, int mode);
 int launch_resample(mclhip_ctx* c, double r, int algo);

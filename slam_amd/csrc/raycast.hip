@@ -310,8 +310,16 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
       int nfac = 0;
       for (int k = lane; k < ((P.dbg & 2) ? 0 : B); k += 64) {
         const double r2 = __longlong_as_double((long long)rmin[k]);
-        const double zd = sqrt(r2);
+        double zd = sqrt(r2);
+        if (P.range_noise) {
+          // augmented MCL: r += randn()*0.15 on every predicted range (mc_localization2.py:166-168);
+          // without any obstacle the reading is min(z_max, z_max + noise) (:170-173)
+          const double term = P.range_noise[p * B + s_perm[k]];
+          zd = P.no_obstacles ? fmin(P.z_max, P.z_max + term) : zd + term;
+        }
         const double ztd = s_zt[k];
+        const bool in_range = (0.0 <= zd) && (zd <= P.z_max);       // range_sensor.py:35, :63
+        const bool in_short = (0.0 <= zd) && (zd <= ztd);           // range_sensor.py:47
         double pkd;
         if constexpr (sizeof(R) == 4) {
           // float32 mode: the two exponentials in float32, exponents and the mixture itself in
@@ -319,15 +327,17 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
           const double d = zd - ztd;
           const float e_hit = exp((float)((d * d) * neg_half_inv_s2));
           const float e_short = exp((float)(-P.lambda * zd));
-          pkd = (double)e_hit * (P.c_hit * P.w_hit) + ((zd <= ztd) ? (double)e_short * (s_el[k] * P.w_short) : 0.0) +
-                ((fabs(zd - P.z_max) < 1e-6) ? P.w_max : 0.0) + P.p_rand * P.w_rand;
+          pkd = (in_range ? (double)e_hit * (P.c_hit * P.w_hit) : 0.0) +
+                (in_short ? (double)e_short * (s_el[k] * P.w_short) : 0.0) +
+                ((fabs(zd - P.z_max) < 1e-6) ? P.w_max : 0.0) + (in_range ? P.p_rand * P.w_rand : 0.0);
         } else {
-          // range_sensor.py:31-67, operation by operation; 0 <= z <= z_max holds by construction
+          // range_sensor.py:31-67, operation by operation
           const double d = zd - ztd;
-          const double p_hit = P.c_hit * exp(-0.5 * (d * d) / P.sigma2);
-          const double p_short = (zd <= ztd) ? s_el[k] * exp(-P.lambda * zd) : 0.0;
+          const double p_hit = in_range ? P.c_hit * exp(-0.5 * (d * d) / P.sigma2) : 0.0;
+          const double p_short = in_short ? s_el[k] * exp(-P.lambda * zd) : 0.0;
           const double p_max = (fabs(zd - P.z_max) < 1e-6) ? 1.0 : 0.0;
-          pkd = p_hit * P.w_hit + p_short * P.w_short + p_max * P.w_max + P.p_rand * P.w_rand;
+          const double p_rand = in_range ? P.p_rand : 0.0;
+          pkd = p_hit * P.w_hit + p_short * P.w_short + p_max * P.w_max + p_rand * P.w_rand;
         }
         prod *= pkd;
         if (++nfac == 16) {
@@ -366,10 +376,12 @@ static size_t ray_lds_bytes(int B, int G, int NB, int n_ring, bool aux) {
 }
 
 int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, const uint8_t* pm, int64_t n,
-                   int dtype, double* w_out, double* logw_out, double* ranges_out, int32_t* hits_out) {
+                   int dtype, double* w_out, double* logw_out, double* ranges_out, int32_t* hits_out,
+                   const double* range_noise) {
   const bool product = w_out != nullptr;
   if (n <= 0) return MCLHIP_OK;
   RayParams P = make_ray_params(c);
+  P.range_noise = range_noise;
   const bool stage = ranges_out != nullptr;
   const size_t lds = ray_lds_bytes(P.B, P.G, P.NB, P.n_ring, stage || product);
   if (lds > 64 * 1024) return fail(c, MCLHIP_E_LIMIT, "beam table does not fit the kernel's LDS budget");

@@ -388,6 +388,38 @@ __global__ void gather_kernel(const int64_t* __restrict__ idx, int64_t n, const 
   w2[m] = w[s];
 }
 
+
+#define MCL_TRY_W(expr) do { int rc__ = (expr); if (rc__ != MCLHIP_OK) return rc__; } while (0)
+
+// c->cdf_exact[i] = the strictly sequential float64 running sum of v[0..i] (== np.cumsum), in parallel
+static int build_exact_cdf(mclhip_ctx* c, const double* wn, int64_t n) {
+  const unsigned g = (unsigned)((n + 255) / 256);
+  const int ntile = (int)((n + kScanTile - 1) / kScanTile);
+  // approximate inclusive scan of the normalised weights
+  LoadF64 lf{wn};
+  StoreF64 sf{c->cdf_approx};
+  hipLaunchKernelGGL((scan_reduce_kernel<double, LoadF64>), dim3(ntile), dim3(kScanBlock), 0, c->stream, lf, n,
+                     (double*)c->blk_a);
+  hipLaunchKernelGGL((scan_blocks_kernel<double>), dim3(1), dim3(kScanBlock), 0, c->stream, (double*)c->blk_a,
+                     ntile);
+  hipLaunchKernelGGL((scan_apply_kernel<double, LoadF64, StoreF64>), dim3(ntile), dim3(kScanBlock), 0, c->stream,
+                     lf, sf, n, (const double*)c->blk_a);
+  // integer increments + irregular flags, scanned together
+  ClassifyLoader cl{c->cdf_approx, wn, 0, 0.0};
+  StoreKF sk{(unsigned long long*)c->kscan, c->fscan, (IrrRecord*)c->irr, wn, 0};
+  hipLaunchKernelGGL((scan_reduce_kernel<KF, ClassifyLoader>), dim3(ntile), dim3(kScanBlock), 0, c->stream, cl, n,
+                     (KF*)c->blk_b);
+  hipLaunchKernelGGL((scan_blocks_kernel<KF>), dim3(1), dim3(kScanBlock), 0, c->stream, (KF*)c->blk_b, ntile);
+  hipLaunchKernelGGL((scan_apply_kernel<KF, ClassifyLoader, StoreKF>), dim3(ntile), dim3(kScanBlock), 0, c->stream,
+                     cl, sk, n, (const KF*)c->blk_b);
+  hipLaunchKernelGGL(replay_kernel, dim3(1), dim3(64), 0, c->stream, (const IrrRecord*)c->irr, c->fscan, n,
+                     (int64_t)0, (RunBase*)c->bases);
+  hipLaunchKernelGGL(finalize_cdf_kernel, dim3(g), dim3(256), 0, c->stream, (const unsigned long long*)c->kscan,
+                     c->fscan, (const RunBase*)c->bases, n, 0ull, 0u, c->cdf_exact);
+  MCL_HIP(c, hipGetLastError());
+  return MCLHIP_OK;
+}
+
 template <typename T>
 static int resample_typed(mclhip_ctx* c, double r, int algo) {
   const int64_t n = c->M;
@@ -400,28 +432,7 @@ static int resample_typed(mclhip_ctx* c, double r, int algo) {
                        (const T*)c->py[a], (const T*)c->pth[a], wn, (T*)c->px[b], (T*)c->py[b], (T*)c->pth[b],
                        c->w[b]);
   } else {
-    const int ntile = (int)((n + kScanTile - 1) / kScanTile);
-    // approximate inclusive scan of the normalised weights
-    LoadF64 lf{wn};
-    StoreF64 sf{c->cdf_approx};
-    hipLaunchKernelGGL((scan_reduce_kernel<double, LoadF64>), dim3(ntile), dim3(kScanBlock), 0, c->stream, lf, n,
-                       (double*)c->blk_a);
-    hipLaunchKernelGGL((scan_blocks_kernel<double>), dim3(1), dim3(kScanBlock), 0, c->stream, (double*)c->blk_a,
-                       ntile);
-    hipLaunchKernelGGL((scan_apply_kernel<double, LoadF64, StoreF64>), dim3(ntile), dim3(kScanBlock), 0, c->stream,
-                       lf, sf, n, (const double*)c->blk_a);
-    // integer increments + irregular flags, scanned together
-    ClassifyLoader cl{c->cdf_approx, wn, 0, 0.0};
-    StoreKF sk{(unsigned long long*)c->kscan, c->fscan, (IrrRecord*)c->irr, wn, 0};
-    hipLaunchKernelGGL((scan_reduce_kernel<KF, ClassifyLoader>), dim3(ntile), dim3(kScanBlock), 0, c->stream, cl, n,
-                       (KF*)c->blk_b);
-    hipLaunchKernelGGL((scan_blocks_kernel<KF>), dim3(1), dim3(kScanBlock), 0, c->stream, (KF*)c->blk_b, ntile);
-    hipLaunchKernelGGL((scan_apply_kernel<KF, ClassifyLoader, StoreKF>), dim3(ntile), dim3(kScanBlock), 0, c->stream,
-                       cl, sk, n, (const KF*)c->blk_b);
-    hipLaunchKernelGGL(replay_kernel, dim3(1), dim3(64), 0, c->stream, (const IrrRecord*)c->irr, c->fscan, n,
-                       (int64_t)0, (RunBase*)c->bases);
-    hipLaunchKernelGGL(finalize_cdf_kernel, dim3(g), dim3(256), 0, c->stream, (const unsigned long long*)c->kscan,
-                       c->fscan, (const RunBase*)c->bases, n, 0ull, 0u, c->cdf_exact);
+    MCL_TRY_W(build_exact_cdf(c, wn, n));
     hipLaunchKernelGGL(search_gather_kernel<T>, dim3(g), dim3(256), 0, c->stream, c->cdf_exact, n, r,
                        (const T*)c->px[a], (const T*)c->py[a], (const T*)c->pth[a], wn, (T*)c->px[b], (T*)c->py[b],
                        (T*)c->pth[b], c->w[b], c->idx);
@@ -606,6 +617,62 @@ int launch_unpack_resample(mclhip_ctx* c, const double* d_rows, int64_t L, int64
                        c->idx);
   MCL_HIP(c, hipGetLastError());
   c->cur = b;
+  return MCLHIP_OK;
+}
+
+
+// ===========================================================================
+// Augmented MCL (mc_localization2.py): running mean of the raw weights and
+// random-pose injection.
+// ===========================================================================
+__global__ void scale_by_kernel(const double* __restrict__ w, double* __restrict__ out, int64_t n, double m) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = w[i] / m;  // w[m] / M (mc_localization2.py:246)
+}
+
+__global__ void copy_last_kernel(const double* __restrict__ cdf, int64_t n, double* __restrict__ scal) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) scal[2] = cdf[n - 1];
+}
+
+// scal[2] = w_avg: `w_avg += w[m] / M` over m = 0..M-1, the same strictly sequential chain the
+// order-exact scan reproduces, so the result is bit-equal to the reference's loop
+int launch_mean_weight(mclhip_ctx* c) {
+  const int64_t n = c->M;
+  const unsigned g = (unsigned)((n + 255) / 256);
+  double* tmp = c->w[1 - c->cur];  // the gather target is free between sample and resample
+  hipLaunchKernelGGL(scale_by_kernel, dim3(g), dim3(256), 0, c->stream, c->w[c->cur], tmp, n, (double)n);
+  MCL_TRY_W(build_exact_cdf(c, tmp, n));
+  hipLaunchKernelGGL(copy_last_kernel, dim3(1), dim3(64), 0, c->stream, c->cdf_exact, n, c->scal);
+  MCL_HIP(c, hipGetLastError());
+  return MCLHIP_OK;
+}
+
+template <typename T>
+__global__ void inject_kernel(const int64_t* __restrict__ rows, const double* __restrict__ poses, int64_t n_inj,
+                              T* __restrict__ x, T* __restrict__ y, T* __restrict__ th, double* __restrict__ w,
+                              double w_value, int set_weight) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_inj) return;
+  const int64_t m = rows[j];
+  x[m] = (T)poses[3 * j];
+  y[m] = (T)poses[3 * j + 1];
+  th[m] = (T)poses[3 * j + 2];
+  if (set_weight) w[m] = w_value;  // Wt.append(1.0/self.M)  (mc_localization2.py:288)
+}
+
+int launch_inject(mclhip_ctx* c, const int64_t* d_rows, const double* d_poses, int64_t n_inj, int which_buffer,
+                  bool set_weight) {
+  if (n_inj <= 0) return MCLHIP_OK;
+  const unsigned g = (unsigned)((n_inj + 255) / 256);
+  const int b = which_buffer;
+  const double wv = 1.0 / (double)c->M;
+  if (c->dtype == MCLHIP_F32)
+    hipLaunchKernelGGL(inject_kernel<float>, dim3(g), dim3(256), 0, c->stream, d_rows, d_poses, n_inj,
+                       (float*)c->px[b], (float*)c->py[b], (float*)c->pth[b], c->w[b], wv, set_weight ? 1 : 0);
+  else
+    hipLaunchKernelGGL(inject_kernel<double>, dim3(g), dim3(256), 0, c->stream, d_rows, d_poses, n_inj,
+                       (double*)c->px[b], (double*)c->py[b], (double*)c->pth[b], c->w[b], wv, set_weight ? 1 : 0);
+  MCL_HIP(c, hipGetLastError());
   return MCLHIP_OK;
 }
 

@@ -283,3 +283,48 @@ def test_device_noise_statistics():
     ctx.set_particles(X0)
     ctx.sample(1.5, 0.0, 0.1, ALPHA, [5.0, 5.0], None, seed=1234)
     assert np.array_equal(ctx.get_particles()[0], X)  # same seed, same draws
+
+
+@pytest.mark.parametrize("name", ["amcl_seed0", "amcl_seed4"])
+def test_augmented_mcl_stages(name):
+    """mc_localization2.py through mclhip_sample_augmented / mclhip_resample_augmented."""
+    g = load(name)
+    L = _lib()
+    ctx = L.Context(0, L.F64)
+    grid = np.load(os.path.join(GOLDEN, "grid_map_g.npy"))
+    ctx.set_map(grid, O.RES_X, O.RES_Y)
+    _sensor(ctx, list(g["sensor_angles"]))
+    for s in steps(g):
+        ctx.set_particles(s["X_in"])
+        w_avg = ctx.sample_augmented(1.5, 0.0, 0.1, ALPHA, s["z_meas"], s["noise"], s["range_noise"])
+        X, w, _ = ctx.get_particles()
+        assert rel_err(X, s["X_motion"]) < 1e-12
+        assert np.array_equal(w == 0, s["w_raw"] == 0)
+        assert rel_err(w, s["w_raw"]) < 1e-11
+        assert abs(w_avg - s["w_avg"]) <= 1e-11 * abs(s["w_avg"])
+        assert w_avg == O.sequential_mean(w)          # the running mean is the exact sequential chain
+        # resampling contract on the reference's own weights
+        ctx.set_particles(s["X_motion"], s["w_raw"])
+        assert ctx.normalise(0) == s["w_sum"]
+        ctx.resample_augmented(float(s["r"]), s["inj_rows"], s["inj_poses"])
+        X2, w2, _ = ctx.get_particles()
+        assert np.array_equal(X2, s["X_out"]) and np.array_equal(w2, s["w_out"])
+
+
+def test_augmented_dropin_class_follows_reference_run():
+    from slam_amd.mc_localization2 import MCLocalization, res_x, res_y
+    g = load("amcl_seed0")
+    grid = np.load(os.path.join(GOLDEN, "grid_map_g.npy"))
+    np.random.seed(0)
+    x0 = np.array([20 * res_x, 30 * res_y, 0], dtype=np.float32)
+    mcl = MCLocalization(x0, grid, M=300)
+    mcl.initialize(x0)
+    for t, s in enumerate(steps(g)[:4]):   # later steps have their slow mean overridden in the fixture
+        assert rel_err(mcl.X, s["X_in"]) < 1e-12
+        mcl.sample([1.5, 0], 0.1)
+        assert np.array_equal(np.asarray(mcl.sensor_ranges), s["z_meas"])
+        assert abs(mcl.w_slow - s["w_slow"]) <= 1e-11 * abs(s["w_slow"])
+        assert abs(mcl.w_fast - s["w_fast"]) <= 1e-11 * abs(s["w_fast"])
+        mcl.resample()
+        assert np.array_equal(mcl.last_injected, s["inj_rows"])
+        assert rel_err(mcl.X, s["X_out"]) < 1e-12

@@ -115,3 +115,33 @@ def test_sum12_matches_numpy_sum():
     s = O.sum12(ints)
     for i in range(len(ints)):
         assert s[i] == (ints[i] * 0.001).sum()
+
+
+@pytest.mark.parametrize("name", ["amcl_seed0", "amcl_seed4"])
+def test_augmented_mcl_stages_bit_exact(name):
+    """mc_localization2.py: noisy predicted ranges, running weight means, injection."""
+    g = load(name)
+    grid = np.load(__import__("os").path.join(__import__("util").GOLDEN, "grid_map_g.npy"))
+    angles = [int(a) for a in g["sensor_angles"]]
+    sp = O.SensorParams()
+    lut, cell = O.obstacle_lut(grid)
+    for s in steps(g):
+        x_in = s["x_gt_in"].astype(np.float32) if bool(s["x_gt_in_is_f32"]) else s["x_gt_in"]
+        x_gt, _ = O.motion_single(x_in, (1.5, 0), 0.1, grid)
+        assert np.array_equal(x_gt, s["x_gt_out"])
+        z, _ = O.sector_query(x_gt, lut, cell, angles)
+        assert np.array_equal(z, s["z_meas"])
+        X, pm = O.motion(s["X_in"], (1.5, 0), 0.1, grid, s["noise"])
+        assert np.array_equal(X, s["X_motion"])
+        R, _ = O.sector_query_batch(X, lut, cell, angles)
+        w, _ = O.amcl_weights(R, s["range_noise"], z, pm, sp)
+        assert np.array_equal(w, s["w_raw"])
+        w_avg = O.sequential_mean(w)
+        assert w_avg == s["w_avg"]
+        ws, wf = O.amcl_rates(s["w_slow_in"], s["w_fast_in"], w_avg)
+        assert ws == s["w_slow"] and wf == s["w_fast"]
+        assert max(0.0, 1 - s["w_fast_rs"] / s["w_slow_rs"]) == s["p_random"]
+        wn = O.normalise(w)
+        Xo, wo, _ = O.amcl_resample(X, wn, float(s["r"]), s["inj_rows"], s["inj_poses"])
+        assert np.array_equal(Xo, s["X_out"])
+        assert np.array_equal(wo, s["w_out"])

@@ -410,9 +410,96 @@ def case_motion_only():
     print("wrote motion_only")
 
 
+def case_amcl():
+    """Augmented MCL (mc_localization2.py): sample with noisy predicted ranges + running weight
+    means, resample with random-pose injection.  The random draws are re-derived from the saved
+    generator state in the order the reference consumes them and checked against its end state."""
+    import mc_localization2 as ref2
+    map_g = load_ref_map()
+    for seed, M, nsteps in ((0, 300, 8), (4, 200, 4)):
+        np.random.seed(seed)
+        x0 = np.array([20 * ref2.res_x, 30 * ref2.res_y, 0], dtype=np.float32)
+        obj = ref2.MCLocalization(np.array(x0), map_g)
+        obj.M = M
+        obj.X = np.zeros([M, 3])
+        obj.w = np.ones(M) / M
+        ref2.mcl = obj
+        obj.x_gt = x0
+        obj.initialize(x0)
+        B = len(obj.sensor_angles)
+        rec = []
+        for t in range(nsteps):
+            s = {}
+            s["X_in"] = obj.X.copy()
+            s["x_gt_in"] = np.array(obj.x_gt).copy()
+            s["x_gt_in_is_f32"] = np.array(np.asarray(obj.x_gt).dtype == np.float32)
+            s["w_slow_in"] = np.float64(obj.w_slow)
+            s["w_fast_in"] = np.float64(obj.w_fast)
+            st = np.random.get_state()
+            with contextlib.redirect_stdout(io.StringIO()):
+                obj.sample([1.5, 0], 0.1)
+            st_after = np.random.get_state()
+            np.random.set_state(st)
+            ints = np.zeros((M, 3, 12), np.int16)
+            rn = np.zeros((M, B))
+            for m in range(M):
+                for j in range(3):
+                    ints[m, j] = np.random.randint(-1000, 1000, size=12)
+                for k in range(B):
+                    rn[m, k] = np.random.randn() * 0.15
+            assert all(np.array_equal(a, b) if isinstance(a, np.ndarray) else a == b
+                       for a, b in zip(np.random.get_state(), st_after)), "sample stream mismatch"
+            s["noise"], s["range_noise"] = ints, rn
+            s["X_motion"] = obj.X.copy()
+            s["x_gt_out"] = np.array(obj.x_gt, np.float64)
+            s["z_meas"] = np.array(obj.sensor_ranges, np.float64)
+            s["w_raw"] = obj.w.copy()
+            s["w_avg"] = np.float64(obj.w_avg)
+            s["w_slow"] = np.float64(obj.w_slow)
+            s["w_fast"] = np.float64(obj.w_fast)
+            s["w_sum"] = np.float64(np.sum(obj.w))
+            if t >= nsteps - 3:
+                # state input of resample(): a slow mean above the fast one makes it inject
+                obj.w_slow = obj.w_fast / (0.7 if t == nsteps - 3 else 0.2)
+            s["w_slow_rs"] = np.float64(obj.w_slow)
+            s["w_fast_rs"] = np.float64(obj.w_fast)
+            st = np.random.get_state()
+            with contextlib.redirect_stdout(io.StringIO()):
+                obj.resample()
+            st_after = np.random.get_state()
+            np.random.set_state(st)
+            s["r"] = np.float64(np.random.rand() * 1 / M)
+            with np.errstate(all="ignore"):
+                p_random = max(0.0, 1 - obj.w_fast / obj.w_slow)
+            rows, poses = [], []
+            for m in range(M):
+                if np.random.rand() <= p_random:
+                    while True:
+                        x = np.random.rand() * ref2.max_x
+                        y = np.random.rand() * ref2.max_y
+                        u, v = int(x / ref2.res_x + 0.5), int(y / ref2.res_y + 0.5)
+                        if not (u >= map_g.shape[1] or v >= map_g.shape[0] or map_g[v, u] < 255):
+                            break
+                    rows.append(m)
+                    poses.append([x, y, np.random.rand() * np.pi * 2.0])
+            assert all(np.array_equal(a, b) if isinstance(a, np.ndarray) else a == b
+                       for a, b in zip(np.random.get_state(), st_after)), "resample stream mismatch"
+            s["p_random"] = np.float64(p_random)
+            s["inj_rows"] = np.array(rows, np.int64)
+            s["inj_poses"] = np.array(poses, np.float64).reshape(-1, 3)
+            s["X_out"] = obj.X.copy()
+            s["w_out"] = obj.w.copy()
+            rec.append(s)
+        print("amcl seed", seed, "injections per step", [len(x["inj_rows"]) for x in rec])
+        save_steps("amcl_seed%d" % seed, rec, {"sensor_angles": np.array(obj.sensor_angles, np.float64),
+                                               "x0": x0, "seed": np.array(seed)})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["demo", "robot", "px", "resample", "motion", "synth"]
+    which = sys.argv[1:] or ["demo", "robot", "px", "resample", "motion", "synth", "amcl"]
+    if "amcl" in which:
+        case_amcl()
     if "demo" in which:
         case_reference_demo()
     if "robot" in which:
