@@ -47,6 +47,7 @@ RayParams make_ray_params(const mclhip_ctx* c) {
   P.p_rand = 1 / c->z_max;                               // range_sensor.py:64
   { const char* d = getenv("MCLHIP_ABLATE"); P.dbg = d ? atoi(d) : 0; }
   P.range_noise = nullptr;
+  P.stamps = c->stamps;
   P.no_obstacles = c->n_obstacles == 0 ? 1 : 0;
   return P;
 }
@@ -233,6 +234,8 @@ int mclhip_create(mclhip_ctx** out, int device, int dtype) {
   e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMalloc((void**)&c->scal, 8 * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&c->stamps, 16 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMemset(c->stamps, 0, 16 * sizeof(unsigned long long));
   if (e != hipSuccess) {
     fail(nullptr, MCLHIP_E_HIP, std::string("context set-up failed: ") + hipGetErrorString(e));
     delete c;
@@ -249,7 +252,7 @@ void mclhip_destroy(mclhip_ctx* c) {
   void* ptrs[] = {c->obst, c->freeb, c->tile_off, c->cells, c->tab_sorted, c->tab_orig, c->perm, c->lut, c->relx, c->zt, c->etalam, c->zmeas_stage, c->ring,
                   c->px[0], c->px[1], c->py[0], c->py[1], c->pth[0], c->pth[1], c->w[0], c->w[1], c->logw, c->pm,
                   c->sx, c->sy, c->sth, c->sw, c->chunk_sums, c->scal, c->cdf_approx, c->cdf_exact, c->kscan,
-                  c->fscan, c->blk_a, c->blk_b, c->irr, c->bases, c->idx, c->noise, c->counters, c->range_noise, c->inj_rows,
+                  c->fscan, c->blk_a, c->blk_b, c->irr, c->bases, c->idx, c->noise, c->counters, c->range_noise, c->inj_rows, c->stamps,
                   c->inj_poses, c->g_records, c->g_bases,
                   c->rows_send, c->rows_recv, c->small_d, c->small_i};
   for (void* p : ptrs)
@@ -334,6 +337,7 @@ int mclhip_set_sensor(mclhip_ctx* c, const double* angles_deg, int B, double z_m
   for (int k = 0; k < B; ++k)
     if (ts[k] - c->ts_min >= two_pi - 2.0 * reach - 1e-6) ++G;
   if (G > B - 1) G = B > 1 ? B - 1 : 0;   // never an image of every beam
+  if (G > 64) return fail(c, MCLHIP_E_LIMIT, "more than 64 beams within one sector width of the 0/2pi seam");
   for (int k = B - G; k < B; ++k) relx.push_back((float)((ts[k] - c->ts_min) - two_pi));
   for (int k = 0; k < B; ++k) relx.push_back((float)(ts[k] - c->ts_min));
   c->G = G;
@@ -835,6 +839,13 @@ int mclhip_timing_enable(mclhip_ctx* c, int on) {
 }
 
 int mclhip_timing_get(mclhip_ctx* c, int which, int64_t* launches, double* total_ms) {
+  if (c && which >= 100 && which < 116 && c->stamps) {   // profiling build: cycles of kernel section which-100
+    unsigned long long v = 0;
+    (void)hipMemcpy(&v, c->stamps + (which - 100), sizeof(v), hipMemcpyDeviceToHost);
+    if (launches) *launches = (int64_t)v;
+    if (total_ms) *total_ms = (double)v;
+    return MCLHIP_OK;
+  }
   if (!c || which < 0 || which > 2) return MCLHIP_E_ARG;
   if (launches) *launches = c->t_launch[which];
   if (total_ms) *total_ms = c->t_ms[which];

@@ -52,6 +52,7 @@ struct RayParams {
   int dbg;               // profiling ablations (0 in production)
   const double* range_noise;  // [n][B] additive noise on the predicted ranges, caller beam order (augmented MCL) or null
   int no_obstacles;      // the map holds no obstacle cell
+  unsigned long long* stamps;  // profiling build only: cycles per kernel section
 };
 
 struct MotionParams {
@@ -130,6 +131,7 @@ struct mclhip_ctx {
   double* inj_poses = nullptr;
   int64_t inj_cap = 0;
   uint32_t* counters = nullptr;  // small device counters
+  unsigned long long* stamps = nullptr;  // [16] cycles per section (profiling build of the sector query)
 
   // multi-GPU: this context's slice of one global particle vector
   int64_t first_index = 0, m_total = 0;

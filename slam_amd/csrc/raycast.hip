@@ -33,7 +33,7 @@ namespace mcl {
 constexpr double kTwoPi = 6.283185307179586;  // == np.pi*2.0
 constexpr int kWavesPerBlock = 4;
 constexpr int kGroup = 8;           // beams examined per step of the matching loop
-constexpr int kWaveScratch = 4 * 64;  // u32 words of per-wave LDS scratch for the tile walk
+constexpr int kWaveScratch = 6 * 64;  // u32 words of per-wave LDS scratch: tile walk (4 x 64) + ring of waiting cells (128)
 
 // ---- cross-lane helpers on the DPP path (no LDS round trip) ----------------
 #define MCL_DPP_I32(old, v, ctrl, rmask) __builtin_amdgcn_update_dpp((old), (v), (ctrl), (rmask), 0xf, false)
@@ -69,6 +69,13 @@ __device__ inline double wave_sum(double v) {
                               (unsigned int)__builtin_amdgcn_readlane((int)__double_as_longlong(v), 63));
 }
 
+// Profiling build (-DMCL_STAMPS): cycles spent per section, summed over waves, in P.stamps.
+#ifdef MCL_STAMPS
+#define STAMP(i) do { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); acc[i] += t__ - t_last; t_last = t__; } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 #ifndef MCL_RAY_WAVES
 #define MCL_RAY_WAVES 3
 #endif
@@ -84,10 +91,11 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
   double* s_zt = s_ts + B;                                        // [B] measured range, sorted order
   double* s_el = s_zt + B;                                        // [B] eta*lambda, sorted order
   unsigned long long* s_rmin_all = reinterpret_cast<unsigned long long*>(s_el + B);
-  unsigned long long* s_aux_all = s_rmin_all + (size_t)kWavesPerBlock * B;
-  unsigned int* s_walk_all = reinterpret_cast<unsigned int*>(s_aux_all + (size_t)((STAGE || PRODUCT) ? kWavesPerBlock * B : 0));
+  const int NXP = P.G + B + kGroup;                              // extended table + one group of padding
+  unsigned long long* s_aux_all = s_rmin_all + (size_t)kWavesPerBlock * NXP;
+  unsigned int* s_walk_all = reinterpret_cast<unsigned int*>(s_aux_all + (size_t)((STAGE || PRODUCT) ? kWavesPerBlock * NXP : 0));
   float* s_relx = reinterpret_cast<float*>(s_walk_all + (size_t)kWavesPerBlock * kWaveScratch);  // [G + B] extended angle table
-  unsigned short* s_perm = reinterpret_cast<unsigned short*>(s_relx + (P.G + B));
+  unsigned short* s_perm = reinterpret_cast<unsigned short*>(s_relx + NXP);
   unsigned short* s_lut = s_perm + B;
   unsigned short* s_ring = s_lut + NB;                            // [n_ring] (dty+128) << 8 | (dtx+128)
 
@@ -99,19 +107,20 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
       s_el[k] = P.etalam[k];
     }
   }
-  for (int k = threadIdx.x; k < P.G + B; k += blockDim.x) s_relx[k] = P.relx[k];
+  for (int k = threadIdx.x; k < NXP; k += blockDim.x) s_relx[k] = (k < P.G + B) ? P.relx[k] : 1.0e30f;  // padding: beyond any window
   for (int k = threadIdx.x; k < NB; k += blockDim.x) s_lut[k] = P.lut[k];
   for (int k = threadIdx.x; k < P.n_ring; k += blockDim.x) s_ring[k] = P.ring[k];
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
-  unsigned long long* const rmin = s_rmin_all + (size_t)wv * B;   // per sorted beam: bits of the smallest r2
-  unsigned long long* const aux = s_aux_all + (size_t)wv * B;     // STAGE: hit cell; PRODUCT: p_k in caller order
+  unsigned long long* const rmin = s_rmin_all + (size_t)wv * NXP;  // per extended-table entry: bits of the smallest r2
+  unsigned long long* const aux = s_aux_all + (size_t)wv * NXP;    // STAGE: hit cell per entry; PRODUCT: p_k in caller order
   unsigned int* const w_incl = s_walk_all + (size_t)wv * kWaveScratch;  // inclusive prefix of list lengths per lane
   unsigned int* const w_split = w_incl + 64;                      // first slot of the lane's second tile
   unsigned int* const w_adj_a = w_split + 64;                     // cells[] index minus slot, first tile
   unsigned int* const w_adj_b = w_adj_a + 64;                     // the same, second tile
+  unsigned int* const ring = w_adj_b + 64;                        // [128] cells waiting to be matched
 
   const unsigned long long r2max_bits = (unsigned long long)__double_as_longlong(P.r2max);
   const float disk_r = (float)(P.z_max * (1.0 + 1e-5) + 0.02 * (P.res_x < P.res_y ? P.res_x : P.res_y));
@@ -126,14 +135,19 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
   const bool seam = span < kTwoPi - 1e-9;   // images of the top beams exist: one window covers both sides of the seam
   const float sure_in = (float)(P.half - kEdgeEps), sure_out = (float)(P.half + kEdgeEps);
 
+#ifdef MCL_STAMPS
+  unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_last = __builtin_amdgcn_s_memtime();
+#endif
   const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
   int64_t p = (int64_t)blockIdx.x * kWavesPerBlock + wv;
   T nx = (T)0, ny = (T)0, nth = (T)0;
   if (p < n) { nx = xs[p]; ny = ys[p]; nth = ths[p]; }
   for (; p < n; p += stride) {
+    STAMP(7);
     const double x = (double)nx, y = (double)ny, th = (double)nth;
     if (p + stride < n) { nx = xs[p + stride]; ny = ys[p + stride]; nth = ths[p + stride]; }  // next pose in flight
-    for (int k = lane; k < B; k += 64) {
+    for (int k = lane; k < NXP; k += 64) {
       rmin[k] = r2max_bits;
       if (STAGE) aux[k] = 0xffffffffull;
     }
@@ -144,7 +158,7 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
     const bool pose_ok = (fabs(fxc) < 1.0e6) && (fabs(fyc) < 1.0e6);
     const int tcx = pose_ok ? ((int)floor(fxc)) >> 3 : 0;
     const int tcy = pose_ok ? ((int)floor(fyc)) >> 3 : 0;
-    const int nt = (pose_ok && fabs(th) < INFINITY && !(P.dbg & 4)) ? P.n_ring : 0;  // NaN / infinite headings match no beam
+    const int nt = (pose_ok && fabs(th) < INFINITY) ? P.n_ring : 0;  // NaN / infinite headings match no beam
     const float xf = (float)x, yf = (float)y;
 
     // (first index into cells[], list length) of ring entry t; empty outside the map or when no
@@ -174,8 +188,8 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
       const double oy = (double)((float)row * P.res_yf);
       const double dx = ox - x, dy = oy - y;              // :124-125, float64
       const double r2 = dx * dx + dy * dy;                // :126
-      if (valid && r2 <= P.r2max && !(P.dbg & 1)) {       // :127
-        float af = (P.dbg & 8) ? (float)dy : atan2f((float)dy, (float)dx);
+      if (valid && r2 <= P.r2max) {       // :127
+        float af = atan2f((float)dy, (float)dx);
         if (af < 0.0f) af += 6.2831855f;
         const double aa = (double)af;
         const unsigned long long r2bits = (unsigned long long)__double_as_longlong(r2);
@@ -188,6 +202,7 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
         c_hi = c_hi > 1 ? 1 : c_hi;
         double a_exact = 0.0;
         bool have_exact = false;
+        STAMP(4);
         // With the seam images in the table every lane needs one pass (its lowest window; the next
         // window's beams appear as images inside it), so the lanes of a batch stay together.
 #pragma unroll 1
@@ -206,29 +221,27 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
           // beams are visited eight at a time: all sixteen LDS reads of a group are issued
           // before the first use, so their latency is paid once per group, not once per beam
 #pragma unroll 1
-          for (int kb = i0; kb < ((P.dbg & 64) ? 0 : NX); kb += kGroup) {
+          for (int kb = i0; kb < NX; kb += kGroup) {
             float eo[kGroup];
             unsigned long long rm[kGroup];
-            int kx[kGroup];
 #pragma unroll
-            for (int j = 0; j < kGroup; ++j) {
-              const int ii = (kb + j < NX) ? kb + j : NX - 1;
-              eo[j] = s_relx[ii] - centref;                 // bearing offset from the beam's axis
-              kx[j] = ii - G + (ii < G ? B : 0);            // sorted beam index of this table entry
-              rm[j] = rmin[kx[j]];
+            for (int j = 0; j < kGroup; ++j) {               // tables are padded: kb + j needs no bound check
+              eo[j] = s_relx[kb + j] - centref;               // bearing offset from the beam's axis
+              rm[j] = rmin[kb + j];
             }
             unsigned int edge_mask = 0u;
             bool beyond = false;
 #pragma unroll
             for (int j = 0; j < kGroup; ++j) {
               const float ae = fabsf(eo[j]);
-              const bool live = (kb + j < NX) && ((STAGE && phase == 1) ? (rm[j] == r2bits) : (r2bits < rm[j]));
-              beyond = beyond || (eo[j] > reachf);
-              if (live && ae <= sure_in && !(P.dbg & 32)) {
-                if (!STAGE || phase == 0) atomicMin(&rmin[kx[j]], r2bits);
-                else atomicMin(&aux[kx[j]], cellbits);     // lowest row-major index among equally near cells
-              } else if (live && ae < sure_out) {
-                edge_mask |= 1u << j;                       // too close to a sector edge for float32
+              const bool live = (STAGE && phase == 1) ? (rm[j] == r2bits) : (r2bits < rm[j]);
+              const bool hit = live & (ae <= sure_in);
+              const bool edg = live & (ae > sure_in) & (ae < sure_out);   // too close to a sector edge for float32
+              beyond = beyond | (eo[j] > reachf);
+              edge_mask |= edg ? (1u << j) : 0u;
+              if (hit) {
+                if (!STAGE || phase == 0) atomicMin(&rmin[kb + j], r2bits);
+                else atomicMin(&aux[kb + j], cellbits);       // lowest row-major index among equally near cells
               }
             }
             while (edge_mask) {                             // rare: exact float64 bearing
@@ -239,13 +252,13 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
                 if (a_exact < 0.0) a_exact += kTwoPi;       // :134-135
                 have_exact = true;
               }
-              const int ie = kb + j;
-              const int ke = ie - G + (ie < G ? B : 0);
+              const int ie = kb + j;                        // entry of the extended table
+              const int ke = ie - G + (ie < G ? B : 0);     // its beam, sorted order
               const double beta = s_ts[ke] + th;            // :143
               const double de = fabs(beta - a_exact);       // :148
               if ((de <= P.half) || (de >= P.two_pi_lo && de <= P.two_pi_hi)) {  // :149
-                if (!STAGE || phase == 0) atomicMin(&rmin[ke], r2bits);
-                else atomicMin(&aux[ke], cellbits);
+                if (!STAGE || phase == 0) atomicMin(&rmin[ie], r2bits);
+                else atomicMin(&aux[ie], cellbits);
               }
             }
             if (beyond) break;
@@ -254,7 +267,9 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
       }
     };
 
+    STAMP(0);
     for (int phase = 0; phase < (STAGE ? 2 : 1); ++phase) {
+      int q_head = 0, q_count = 0;   // wave-uniform state of the ring of cells waiting to be matched
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       for (int base = 0; base < nt; base += 128) {
         // two ring entries per lane, nearest first
@@ -269,6 +284,7 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
         w_adj_a[lane] = off_a - excl;
         w_adj_b[lane] = off_b - (excl + len_a);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        STAMP(1);
 
         // slot s of the concatenated lists belongs to the first lane whose inclusive prefix exceeds s
         auto fetch = [&](int sb) -> unsigned int {
@@ -282,24 +298,68 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
           return P.cells[idx];
         };
 
+        // Cells of the fetched batch that a float32 distance test (a little generous; the exact
+        // float64 test follows in match_cell) puts within z_max are queued in a 128-entry LDS
+        // ring; whenever 64 are waiting they are matched together, so that the expensive part
+        // runs with (almost) every lane busy although boundary tiles deliver many cells out of range.
         unsigned int e_next = fetch(0);
+        STAMP(2);
         for (int sb = 0; sb < total; sb += 64) {
           const unsigned int e = e_next;
-          if (sb + 64 < total) e_next = fetch(sb + 64);     // next batch in flight while this one is matched
-          match_cell(e, sb + lane < total, phase);
+          if (sb + 64 < total) e_next = fetch(sb + 64);     // next batch in flight while this one is handled
+          STAMP(2);
+          const float cdx = (float)(e & 0xffffu) * P.res_xf - xf;
+          const float cdy = (float)(e >> 16) * P.res_yf - yf;
+          const bool keep = (sb + lane < total) && (cdx * cdx + cdy * cdy <= disk_r2);
+          const unsigned long long km = __ballot(keep);
+          if (keep) {
+            const unsigned int pos = __builtin_amdgcn_mbcnt_hi((unsigned int)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)km, 0u));
+            ring[(q_head + q_count + (int)pos) & 127] = e;
+          }
+          q_count += __popcll(km);
+          STAMP(3);
+          if (q_count >= 64) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            match_cell(ring[(q_head + lane) & 127], true, phase);
+            STAMP(5);
+            q_head = (q_head + 64) & 127;
+            q_count -= 64;
+          }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
+      if (q_count > 0) {                                     // what is left in the ring
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        match_cell(lane < q_count ? ring[(q_head + lane) & 127] : 0u, lane < q_count, phase);
+        STAMP(5);
+        q_count = 0;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      // a beam that also has a seam image keeps the smaller of the two minima in both entries
+      // (entry G + k is beam k; entry g < G is the image of beam B - G + g)
+      if (lane < G) {
+        const int real = B + lane;   // == G + (B - G + lane)
+        if (!STAGE || phase == 0) {
+          const unsigned long long a = rmin[lane], b = rmin[real];
+          const unsigned long long m = a < b ? a : b;
+          rmin[lane] = m;
+          rmin[real] = m;
+        } else {
+          const unsigned long long a = aux[lane], b = aux[real];
+          aux[real] = a < b ? a : b;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
 
     // ranges -> beam mixture -> weight
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (STAGE) {
       for (int k = lane; k < B; k += 64) {
-        const double r2 = __longlong_as_double((long long)rmin[k]);
+        const double r2 = __longlong_as_double((long long)rmin[G + k]);
         const int ko = s_perm[k];
         ranges_out[p * B + ko] = sqrt(r2);  // :160
-        const unsigned int h = (unsigned int)aux[k];
+        const unsigned int h = (unsigned int)aux[G + k];
         hits_out[p * B + ko] = (h == 0xffffffffu) ? -1 : (int32_t)h;
       }
     } else {
@@ -308,8 +368,8 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
       // partial product (sum of logs == log of product; 16 factors >= 1e-3 cannot underflow)
       double ls = 0.0, prod = 1.0;
       int nfac = 0;
-      for (int k = lane; k < ((P.dbg & 2) ? 0 : B); k += 64) {
-        const double r2 = __longlong_as_double((long long)rmin[k]);
+      for (int k = lane; k < B; k += 64) {
+        const double r2 = __longlong_as_double((long long)rmin[G + k]);
         double zd = sqrt(r2);
         if (P.range_noise) {
           // augmented MCL: r += randn()*0.15 on every predicted range (mc_localization2.py:166-168);
@@ -363,14 +423,20 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    STAMP(6);
   }
+#ifdef MCL_STAMPS
+  if (lane == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&P.stamps[i], acc[i]);
+#endif
 }
 
 static size_t ray_lds_bytes(int B, int G, int NB, int n_ring, bool aux) {
+  const int NXP = B + G + kGroup;
   size_t s = (size_t)3 * B * sizeof(double);
-  s += (size_t)kWavesPerBlock * B * sizeof(unsigned long long) * (aux ? 2 : 1);
+  s += (size_t)kWavesPerBlock * NXP * sizeof(unsigned long long) * (aux ? 2 : 1);
   s += (size_t)kWavesPerBlock * kWaveScratch * sizeof(unsigned int);
-  s += (size_t)(B + G) * sizeof(float);
+  s += (size_t)NXP * sizeof(float);
   s += ((size_t)B + NB + n_ring + 2) * sizeof(unsigned short);
   return (s + 15) & ~(size_t)15;
 }
