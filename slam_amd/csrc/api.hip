@@ -24,8 +24,9 @@ size_t kf_bytes();
 
 RayParams make_ray_params(const mclhip_ctx* c) {
   RayParams P;
-  P.tile_off = c->tile_off;
-  P.cells = c->cells;
+  P.nbr_off = c->nbr_off;
+  P.nbr_cells = c->nbr_cells;
+  P.ETW = c->ETW; P.ETH = c->ETH; P.rtx = c->rtx; P.rty = c->rty;
   P.TW = c->TW; P.TH = c->TH; P.W = c->W; P.H = c->H;
   P.res_xf = (float)c->res_x; P.res_yf = (float)c->res_y;
   P.res_x = c->res_x; P.res_y = c->res_y;
@@ -77,6 +78,32 @@ int build_ring_table(mclhip_ctx* c) {
   MCL_HIP(c, hipMalloc((void**)&c->ring, ring.size() * sizeof(uint16_t)));
   MCL_HIP(c, hipMemcpy(c->ring, ring.data(), ring.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   c->n_ring = (int)ring.size();
+  // neighbourhood lists over the tile grid extended by the ring radius
+  c->rtx = rtx; c->rty = rty;
+  c->ETW = c->TW + 2 * rtx; c->ETH = c->TH + 2 * rty;
+  const size_t ne = (size_t)c->ETW * c->ETH;
+  uint32_t* d_cnt = nullptr;
+  MCL_HIP(c, hipMalloc((void**)&d_cnt, ne * sizeof(uint32_t)));
+  int rc = launch_nbr_count(c, d_cnt);
+  std::vector<uint32_t> cnt(ne);
+  hipError_t e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) e = hipMemcpy(cnt.data(), d_cnt, ne * sizeof(uint32_t), hipMemcpyDeviceToHost);
+  (void)hipFree(d_cnt);
+  if (rc != MCLHIP_OK) return rc;
+  if (e != hipSuccess) return fail(c, MCLHIP_E_HIP, std::string("neighbourhood count: ") + hipGetErrorString(e));
+  std::vector<uint32_t> off(ne + 1);
+  uint64_t acc = 0;
+  for (size_t t = 0; t < ne; ++t) { off[t] = (uint32_t)acc; acc += cnt[t]; }
+  if (acc > 0xffffffffull) return fail(c, MCLHIP_E_LIMIT, "neighbourhood lists exceed 2^32 entries (map too large for this z_max)");
+  off[ne] = (uint32_t)acc;
+  if (c->nbr_off) { (void)hipFree(c->nbr_off); c->nbr_off = nullptr; }
+  if (c->nbr_cells) { (void)hipFree(c->nbr_cells); c->nbr_cells = nullptr; }
+  MCL_HIP(c, hipMalloc((void**)&c->nbr_off, (ne + 1) * sizeof(uint32_t)));
+  MCL_HIP(c, hipMalloc((void**)&c->nbr_cells, (acc ? acc : 1) * sizeof(uint32_t)));
+  MCL_HIP(c, hipMemcpy(c->nbr_off, off.data(), (ne + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+  rc = launch_nbr_fill(c);
+  if (rc != MCLHIP_OK) return rc;
+  MCL_HIP(c, hipStreamSynchronize(c->stream));
   c->ring_dirty = false;
   return MCLHIP_OK;
 }
@@ -249,7 +276,7 @@ void mclhip_destroy(mclhip_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  void* ptrs[] = {c->obst, c->freeb, c->tile_off, c->cells, c->tab_sorted, c->tab_orig, c->perm, c->lut, c->relx, c->zt, c->etalam, c->zmeas_stage, c->ring,
+  void* ptrs[] = {c->obst, c->freeb, c->tile_off, c->cells, c->nbr_off, c->nbr_cells, c->tab_sorted, c->tab_orig, c->perm, c->lut, c->relx, c->zt, c->etalam, c->zmeas_stage, c->ring,
                   c->px[0], c->px[1], c->py[0], c->py[1], c->pth[0], c->pth[1], c->w[0], c->w[1], c->logw, c->pm,
                   c->sx, c->sy, c->sth, c->sw, c->chunk_sums, c->scal, c->cdf_approx, c->cdf_exact, c->kscan,
                   c->fscan, c->blk_a, c->blk_b, c->irr, c->bases, c->idx, c->noise, c->counters, c->range_noise, c->inj_rows, c->stamps,

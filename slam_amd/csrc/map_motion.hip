@@ -42,6 +42,63 @@ int launch_build_tiles(mclhip_ctx* c, const uint8_t* d_map) {
 }
 
 // ---------------------------------------------------------------------------
+// Neighbourhood lists.  For every tile of the grid (extended by the ring radius on each side) the
+// obstacle cells of all tiles the ring table names, concatenated nearest tile first: what a
+// particle standing anywhere in that tile has to look at is then one contiguous slice.
+// ---------------------------------------------------------------------------
+__global__ void nbr_count_kernel(const uint32_t* __restrict__ tile_off, int TW, int TH, const uint16_t* __restrict__ ring,
+                                 int n_ring, int rtx, int rty, int ETW, int ETH, uint32_t* __restrict__ cnt) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ETW * ETH) return;
+  const int ty = t / ETW - rty, tx = t % ETW - rtx;
+  uint32_t n = 0;
+  for (int r = 0; r < n_ring; ++r) {
+    const int y = ty + (int)(ring[r] >> 8) - 128, x = tx + (int)(ring[r] & 0xffu) - 128;
+    if (y < 0 || y >= TH || x < 0 || x >= TW) continue;
+    const uint32_t* to = tile_off + ((size_t)y * TW + x);
+    n += to[1] - to[0];
+  }
+  cnt[t] = n;
+}
+
+// one wavefront per extended tile
+__global__ __launch_bounds__(256) void nbr_fill_kernel(const uint32_t* __restrict__ tile_off,
+                                                       const uint32_t* __restrict__ cells, int TW, int TH,
+                                                       const uint16_t* __restrict__ ring, int n_ring, int rtx, int rty,
+                                                       int ETW, int ETH, const uint32_t* __restrict__ nbr_off,
+                                                       uint32_t* __restrict__ nbr_cells) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (t >= ETW * ETH) return;
+  const int ty = t / ETW - rty, tx = t % ETW - rtx;
+  uint32_t out = nbr_off[t];
+  for (int r = 0; r < n_ring; ++r) {
+    const int y = ty + (int)(ring[r] >> 8) - 128, x = tx + (int)(ring[r] & 0xffu) - 128;
+    if (y < 0 || y >= TH || x < 0 || x >= TW) continue;
+    const uint32_t* to = tile_off + ((size_t)y * TW + x);
+    const uint32_t o = to[0], n = to[1] - o;   // n <= 64
+    if ((uint32_t)lane < n) nbr_cells[out + lane] = cells[o + lane];
+    out += n;
+  }
+}
+
+int launch_nbr_count(mclhip_ctx* c, uint32_t* d_cnt) {
+  const int ne = c->ETW * c->ETH;
+  hipLaunchKernelGGL(nbr_count_kernel, dim3((ne + 255) / 256), dim3(256), 0, c->stream, c->tile_off, c->TW, c->TH,
+                     c->ring, c->n_ring, c->rtx, c->rty, c->ETW, c->ETH, d_cnt);
+  MCL_HIP(c, hipGetLastError());
+  return MCLHIP_OK;
+}
+
+int launch_nbr_fill(mclhip_ctx* c) {
+  const int ne = c->ETW * c->ETH;
+  hipLaunchKernelGGL(nbr_fill_kernel, dim3((ne + 3) / 4), dim3(256), 0, c->stream, c->tile_off, c->cells, c->TW, c->TH,
+                     c->ring, c->n_ring, c->rtx, c->rty, c->ETW, c->ETH, c->nbr_off, c->nbr_cells);
+  MCL_HIP(c, hipGetLastError());
+  return MCLHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
 // Per-beam constants that depend only on the measured range z*_k:
 //   etalam_k = 1/(1 - exp(-lambda*z*_k)) * lambda      (range_sensor.py:49-50)
 // ---------------------------------------------------------------------------

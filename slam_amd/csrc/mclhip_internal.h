@@ -22,8 +22,10 @@ constexpr int kScanTile = kScanBlock * kScanItems;
 
 // Everything the sector-query kernel needs about the map and the sensor.
 struct RayParams {
-  const uint32_t* tile_off;  // [TH*TW + 1] start of each 8x8-cell tile's obstacle list in cells[]
-  const uint32_t* cells;     // obstacle cells grouped by tile (row-major tiles, row-major inside): row << 16 | col
+  const uint32_t* nbr_off;   // [ETH*ETW + 1] start of each tile's neighbourhood list in nbr_cells[]
+  const uint32_t* nbr_cells; // per tile: the obstacle cells (row << 16 | col) of every tile that can hold a cell
+                             // within z_max of a point of that tile, nearest tile first
+  int ETW, ETH, rtx, rty;    // the tile grid is extended by rtx / rty tiles on each side (poses just outside the map)
   int TW, TH, W, H;
   float res_xf, res_yf;  // float32 cell size: cell-centre coordinates are float32 products
   double res_x, res_y;
@@ -81,6 +83,9 @@ struct mclhip_ctx {
   uint64_t* freeb = nullptr;    // free-cell bit plane
   uint32_t* tile_off = nullptr; // per-tile obstacle lists: offsets ...
   uint32_t* cells = nullptr;    // ... and entries
+  uint32_t* nbr_off = nullptr;  // per-tile neighbourhood lists (built from the two above and the ring table)
+  uint32_t* nbr_cells = nullptr;
+  int ETW = 0, ETH = 0, rtx = 0, rty = 0;
   int64_t n_obstacles = 0;
 
   // sensor
@@ -164,6 +169,8 @@ int fail(mclhip_ctx* c, int code, const std::string& msg);
 int launch_build_tiles(mclhip_ctx* c, const uint8_t* d_map);
 int launch_beam_table(mclhip_ctx* c);
 int build_ring_table(mclhip_ctx* c);
+int launch_nbr_count(mclhip_ctx* c, uint32_t* d_cnt);
+int launch_nbr_fill(mclhip_ctx* c);
 int launch_motion(mclhip_ctx* c, void* x, void* y, void* th, uint8_t* pm, int64_t n, const MotionParams& mp,
                   const int16_t* d_noise, int dtype);
 int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, const uint8_t* pm, int64_t n,

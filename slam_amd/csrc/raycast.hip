@@ -33,7 +33,7 @@ namespace mcl {
 constexpr double kTwoPi = 6.283185307179586;  // == np.pi*2.0
 constexpr int kWavesPerBlock = 4;
 constexpr int kGroup = 8;           // beams examined per step of the matching loop
-constexpr int kWaveScratch = 6 * 64;  // u32 words of per-wave LDS scratch: tile walk (4 x 64) + ring of waiting cells (128)
+constexpr int kWaveScratch = 128;     // u32 words of per-wave LDS scratch: the ring of cells waiting to be matched
 
 // ---- cross-lane helpers on the DPP path (no LDS round trip) ----------------
 #define MCL_DPP_I32(old, v, ctrl, rmask) __builtin_amdgcn_update_dpp((old), (v), (ctrl), (rmask), 0xf, false)
@@ -97,7 +97,6 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
   float* s_relx = reinterpret_cast<float*>(s_walk_all + (size_t)kWavesPerBlock * kWaveScratch);  // [G + B] extended angle table
   unsigned short* s_perm = reinterpret_cast<unsigned short*>(s_relx + NXP);
   unsigned short* s_lut = s_perm + B;
-  unsigned short* s_ring = s_lut + NB;                            // [n_ring] (dty+128) << 8 | (dtx+128)
 
   for (int k = threadIdx.x; k < B; k += blockDim.x) {
     s_ts[k] = P.tab_sorted[k];
@@ -109,18 +108,13 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
   }
   for (int k = threadIdx.x; k < NXP; k += blockDim.x) s_relx[k] = (k < P.G + B) ? P.relx[k] : 1.0e30f;  // padding: beyond any window
   for (int k = threadIdx.x; k < NB; k += blockDim.x) s_lut[k] = P.lut[k];
-  for (int k = threadIdx.x; k < P.n_ring; k += blockDim.x) s_ring[k] = P.ring[k];
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   unsigned long long* const rmin = s_rmin_all + (size_t)wv * NXP;  // per extended-table entry: bits of the smallest r2
   unsigned long long* const aux = s_aux_all + (size_t)wv * NXP;    // STAGE: hit cell per entry; PRODUCT: p_k in caller order
-  unsigned int* const w_incl = s_walk_all + (size_t)wv * kWaveScratch;  // inclusive prefix of list lengths per lane
-  unsigned int* const w_split = w_incl + 64;                      // first slot of the lane's second tile
-  unsigned int* const w_adj_a = w_split + 64;                     // cells[] index minus slot, first tile
-  unsigned int* const w_adj_b = w_adj_a + 64;                     // the same, second tile
-  unsigned int* const ring = w_adj_b + 64;                        // [128] cells waiting to be matched
+  unsigned int* const ring = s_walk_all + (size_t)wv * kWaveScratch;   // [128] cells waiting to be matched
 
   const unsigned long long r2max_bits = (unsigned long long)__double_as_longlong(P.r2max);
   const float disk_r = (float)(P.z_max * (1.0 + 1e-5) + 0.02 * (P.res_x < P.res_y ? P.res_x : P.res_y));
@@ -142,11 +136,16 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
   const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
   int64_t p = (int64_t)blockIdx.x * kWavesPerBlock + wv;
   T nx = (T)0, ny = (T)0, nth = (T)0;
-  if (p < n) { nx = xs[p]; ny = ys[p]; nth = ths[p]; }
+  unsigned char npm = 0;
+  if (p < n) { nx = xs[p]; ny = ys[p]; nth = ths[p]; if (!STAGE) npm = pm[p]; }
   for (; p < n; p += stride) {
     STAMP(7);
     const double x = (double)nx, y = (double)ny, th = (double)nth;
-    if (p + stride < n) { nx = xs[p + stride]; ny = ys[p + stride]; nth = ths[p + stride]; }  // next pose in flight
+    const bool on_free = npm != 0;
+    if (p + stride < n) {   // next pose in flight
+      nx = xs[p + stride]; ny = ys[p + stride]; nth = ths[p + stride];
+      if (!STAGE) npm = pm[p + stride];
+    }
     for (int k = lane; k < NXP; k += 64) {
       rmin[k] = r2max_bits;
       if (STAGE) aux[k] = 0xffffffffull;
@@ -158,28 +157,17 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
     const bool pose_ok = (fabs(fxc) < 1.0e6) && (fabs(fyc) < 1.0e6);
     const int tcx = pose_ok ? ((int)floor(fxc)) >> 3 : 0;
     const int tcy = pose_ok ? ((int)floor(fyc)) >> 3 : 0;
-    const int nt = (pose_ok && fabs(th) < INFINITY) ? P.n_ring : 0;  // NaN / infinite headings match no beam
+    // the particle's slice of neighbourhood cells; NaN / infinite headings match no beam
+    unsigned int first_cell = 0u, n_cells = 0u;
+    {
+      const int ex = tcx + P.rtx, ey = tcy + P.rty;
+      if (pose_ok && fabs(th) < INFINITY && ex >= 0 && ex < P.ETW && ey >= 0 && ey < P.ETH) {
+        const unsigned int* no = P.nbr_off + ((size_t)ey * P.ETW + ex);
+        first_cell = no[0];
+        n_cells = no[1] - first_cell;
+      }
+    }
     const float xf = (float)x, yf = (float)y;
-
-    // (first index into cells[], list length) of ring entry t; empty outside the map or when no
-    // cell of the tile can be within z_max
-    auto tile_list = [&](int t, unsigned int& off, unsigned int& len) {
-      off = 0u;
-      len = 0u;
-      if (t >= nt) return;
-      const unsigned int rg = s_ring[t];
-      const int ty = tcy + (int)(rg >> 8) - 128, tx = tcx + (int)(rg & 0xffu) - 128;
-      if (ty < 0 || ty >= P.TH || tx < 0 || tx >= P.TW) return;
-      // nearest point of the tile's cell-centre rectangle to the particle
-      const float cx0 = (float)(tx * 8) * P.res_xf, cx1 = (float)(tx * 8 + 7) * P.res_xf;
-      const float cy0 = (float)(ty * 8) * P.res_yf, cy1 = (float)(ty * 8 + 7) * P.res_yf;
-      const float ddx = xf < cx0 ? cx0 - xf : (xf > cx1 ? xf - cx1 : 0.0f);
-      const float ddy = yf < cy0 ? cy0 - yf : (yf > cy1 ? yf - cy1 : 0.0f);
-      if (ddx * ddx + ddy * ddy > disk_r2) return;
-      const unsigned int* to = P.tile_off + ((size_t)ty * P.TW + tx);
-      off = to[0];
-      len = to[1] - off;
-    };
 
     // one cell against the beam table
     auto match_cell = [&](unsigned int e, bool valid, int phase) {
@@ -271,62 +259,32 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
     for (int phase = 0; phase < (STAGE ? 2 : 1); ++phase) {
       int q_head = 0, q_count = 0;   // wave-uniform state of the ring of cells waiting to be matched
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      for (int base = 0; base < nt; base += 128) {
-        // two ring entries per lane, nearest first
-        unsigned int off_a, len_a, off_b, len_b;
-        tile_list(base + 2 * lane, off_a, len_a);
-        tile_list(base + 2 * lane + 1, off_b, len_b);
-        const int incl = wave_incl_scan((int)(len_a + len_b));
-        const int total = __builtin_amdgcn_readlane(incl, 63);
-        const unsigned int excl = (unsigned int)incl - (len_a + len_b);
-        w_incl[lane] = (unsigned int)incl;
-        w_split[lane] = excl + len_a;
-        w_adj_a[lane] = off_a - excl;
-        w_adj_b[lane] = off_b - (excl + len_a);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        STAMP(1);
-
-        // slot s of the concatenated lists belongs to the first lane whose inclusive prefix exceeds s
-        auto fetch = [&](int sb) -> unsigned int {
-          const unsigned int s = (unsigned int)(sb + lane);
-          if ((int)s >= total) return 0u;
-          int u = 0;
-#pragma unroll
-          for (int step = 32; step >= 1; step >>= 1)
-            if (w_incl[u + step - 1] <= s) u += step;
-          const unsigned int idx = (s < w_split[u]) ? w_adj_a[u] + s : w_adj_b[u] + s;
-          return P.cells[idx];
-        };
-
-        // Cells of the fetched batch that a float32 distance test (a little generous; the exact
-        // float64 test follows in match_cell) puts within z_max are queued in a 128-entry LDS
-        // ring; whenever 64 are waiting they are matched together, so that the expensive part
-        // runs with (almost) every lane busy although boundary tiles deliver many cells out of range.
-        unsigned int e_next = fetch(0);
-        STAMP(2);
-        for (int sb = 0; sb < total; sb += 64) {
-          const unsigned int e = e_next;
-          if (sb + 64 < total) e_next = fetch(sb + 64);     // next batch in flight while this one is handled
-          STAMP(2);
-          const float cdx = (float)(e & 0xffffu) * P.res_xf - xf;
-          const float cdy = (float)(e >> 16) * P.res_yf - yf;
-          const bool keep = (sb + lane < total) && (cdx * cdx + cdy * cdy <= disk_r2);
-          const unsigned long long km = __ballot(keep);
-          if (keep) {
-            const unsigned int pos = __builtin_amdgcn_mbcnt_hi((unsigned int)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)km, 0u));
-            ring[(q_head + q_count + (int)pos) & 127] = e;
-          }
-          q_count += __popcll(km);
-          STAMP(3);
-          if (q_count >= 64) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            match_cell(ring[(q_head + lane) & 127], true, phase);
-            STAMP(5);
-            q_head = (q_head + 64) & 127;
-            q_count -= 64;
-          }
+      // Cells of a fetched batch that a float32 distance test (a little generous; the exact
+      // float64 test follows in match_cell) puts within z_max are queued in a 128-entry LDS
+      // ring; whenever 64 are waiting they are matched together, so that the expensive part
+      // runs with (almost) every lane busy although the slice holds many cells out of range.
+      unsigned int e_next = (lane < (int)n_cells) ? P.nbr_cells[first_cell + lane] : 0u;
+      STAMP(2);
+      for (unsigned int sb = 0; sb < n_cells; sb += 64) {
+        const unsigned int e = e_next;
+        if (sb + 64 + lane < n_cells) e_next = P.nbr_cells[first_cell + sb + 64 + lane];   // next batch in flight
+        const float cdx = (float)(e & 0xffffu) * P.res_xf - xf;
+        const float cdy = (float)(e >> 16) * P.res_yf - yf;
+        const bool keep = (sb + lane < n_cells) && (cdx * cdx + cdy * cdy <= disk_r2);
+        const unsigned long long km = __ballot(keep);
+        if (keep) {
+          const unsigned int pos = __builtin_amdgcn_mbcnt_hi((unsigned int)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)km, 0u));
+          ring[(q_head + q_count + (int)pos) & 127] = e;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        q_count += __popcll(km);
+        STAMP(3);
+        if (q_count >= 64) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          match_cell(ring[(q_head + lane) & 127], true, phase);
+          STAMP(5);
+          q_head = (q_head + 64) & 127;
+          q_count -= 64;
+        }
       }
       if (q_count > 0) {                                     // what is left in the ring
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -370,7 +328,15 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
       int nfac = 0;
       for (int k = lane; k < B; k += 64) {
         const double r2 = __longlong_as_double((long long)rmin[G + k]);
-        double zd = sqrt(r2);
+        double zd;
+        if constexpr (sizeof(R) == 4) {
+          // float32 square root refined by one Newton step in float64 (relative error ~1e-14)
+          const float z0 = sqrtf((float)r2);
+          const double z0d = (double)z0;
+          zd = (r2 > 0.0) ? z0d + (r2 - z0d * z0d) * (double)(0.5f / z0) : 0.0;
+        } else {
+          zd = sqrt(r2);
+        }
         if (P.range_noise) {
           // augmented MCL: r += randn()*0.15 on every predicted range (mc_localization2.py:166-168);
           // without any obstacle the reading is min(z_max, z_max + noise) (:170-173)
@@ -417,7 +383,7 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
         for (int k = 0; k < B; ++k) q = q * __longlong_as_double((long long)aux[k]);
       }
       if (lane == 0) {
-        const bool fr = pm[p] != 0;
+        const bool fr = on_free;
         if (PRODUCT) w_out[p] = fr ? q : q * 0.0;  // q * pm (mc_localization.py:240)
         logw_out[p] = fr ? lsd : -INFINITY;
       }
@@ -437,7 +403,8 @@ static size_t ray_lds_bytes(int B, int G, int NB, int n_ring, bool aux) {
   s += (size_t)kWavesPerBlock * NXP * sizeof(unsigned long long) * (aux ? 2 : 1);
   s += (size_t)kWavesPerBlock * kWaveScratch * sizeof(unsigned int);
   s += (size_t)NXP * sizeof(float);
-  s += ((size_t)B + NB + n_ring + 2) * sizeof(unsigned short);
+  s += ((size_t)B + NB + 2) * sizeof(unsigned short);
+  (void)n_ring;
   return (s + 15) & ~(size_t)15;
 }
 
