@@ -217,38 +217,46 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
               eo[j] = s_relx[kb + j] - centref;               // bearing offset from the beam's axis
               rm[j] = rmin[kb + j];
             }
-            unsigned int edge_mask = 0u;
-            bool beyond = false;
+            bool any_edge = false;
 #pragma unroll
             for (int j = 0; j < kGroup; ++j) {
               const float ae = fabsf(eo[j]);
               const bool live = (STAGE && phase == 1) ? (rm[j] == r2bits) : (r2bits < rm[j]);
-              const bool hit = live & (ae <= sure_in);
-              const bool edg = live & (ae > sure_in) & (ae < sure_out);   // too close to a sector edge for float32
-              beyond = beyond | (eo[j] > reachf);
-              edge_mask |= edg ? (1u << j) : 0u;
-              if (hit) {
+              const bool inside = ae <= sure_in, near = ae < sure_out;
+              any_edge = any_edge | (live & (near != inside));   // too close to a sector edge for float32
+              if (live & inside) {
                 if (!STAGE || phase == 0) atomicMin(&rmin[kb + j], r2bits);
                 else atomicMin(&aux[kb + j], cellbits);       // lowest row-major index among equally near cells
               }
             }
-            while (edge_mask) {                             // rare: exact float64 bearing
-              const int j = __ffs((int)edge_mask) - 1;
-              edge_mask &= edge_mask - 1u;
+            if (any_edge) {                                 // rare: exact float64 bearing
               if (!have_exact) {
-                a_exact = atan2(dy, dx);                    // :133
+                // the empty asm pins the evaluation inside this branch (it must not be hoisted and
+                // run for every cell)
+                double dyo = dy, dxo = dx;
+                asm volatile("" : "+v"(dyo), "+v"(dxo));
+                a_exact = atan2(dyo, dxo);                  // :133
                 if (a_exact < 0.0) a_exact += kTwoPi;       // :134-135
                 have_exact = true;
               }
-              const int ie = kb + j;                        // entry of the extended table
-              const int ke = ie - G + (ie < G ? B : 0);     // its beam, sorted order
-              const double beta = s_ts[ke] + th;            // :143
-              const double de = fabs(beta - a_exact);       // :148
-              if ((de <= P.half) || (de >= P.two_pi_lo && de <= P.two_pi_hi)) {  // :149
-                if (!STAGE || phase == 0) atomicMin(&rmin[ie], r2bits);
-                else atomicMin(&aux[ie], cellbits);
+#pragma unroll 1
+              for (int j = 0; j < kGroup; ++j) {
+                const int ie = kb + j;                      // entry of the extended table
+                const float ae = fabsf(s_relx[ie] - centref);
+                const unsigned long long rmj = rmin[ie];
+                const bool live = (STAGE && phase == 1) ? (rmj == r2bits) : (r2bits < rmj);
+                if (live && ae > sure_in && ae < sure_out) {
+                  const int ke = ie - G + (ie < G ? B : 0);   // its beam, sorted order
+                  const double beta = s_ts[ke] + th;          // :143
+                  const double de = fabs(beta - a_exact);     // :148
+                  if ((de <= P.half) || (de >= P.two_pi_lo && de <= P.two_pi_hi)) {  // :149
+                    if (!STAGE || phase == 0) atomicMin(&rmin[ie], r2bits);
+                    else atomicMin(&aux[ie], cellbits);
+                  }
+                }
               }
             }
+            const bool beyond = eo[kGroup - 1] > reachf;    // the table ascends: nothing further can be in reach
             if (beyond) break;
           }
         }
