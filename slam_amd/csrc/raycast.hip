@@ -76,6 +76,15 @@ __device__ inline double wave_sum(double v) {
 #define STAMP(i) do { } while (0)
 #endif
 
+// Counting build (-DMCL_COUNTS): loop trip counts in P.stamps[8..15]; COUNT = once per wave, COUNTL = once per active lane.
+#ifdef MCL_COUNTS
+#define COUNT(i) do { if (lane == (int)__ffsll((unsigned long long)__ballot(1)) - 1) cnt[i] += 1; } while (0)
+#define COUNTL(i) do { cnt[i] += 1; } while (0)
+#else
+#define COUNT(i) do { } while (0)
+#define COUNTL(i) do { } while (0)
+#endif
+
 #ifndef MCL_RAY_WAVES
 #define MCL_RAY_WAVES 3
 #endif
@@ -120,6 +129,8 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
   const float disk_r = (float)(P.z_max * (1.0 + 1e-5) + 0.02 * (P.res_x < P.res_y ? P.res_x : P.res_y));
   const float disk_r2 = disk_r * disk_r;
   const double neg_half_inv_s2 = -0.5 / P.sigma2;
+  const double neg_half_inv_s2_log2e = neg_half_inv_s2 * 1.4426950408889634;
+  const double neg_lambda_log2e = -P.lambda * 1.4426950408889634;
   const double span = P.ts_max - P.ts_min;
   const double reach = P.half + 2.0 * kEdgeEps;   // candidate window half-width
   const double inv_two_pi = 1.0 / kTwoPi;
@@ -132,6 +143,9 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
 #ifdef MCL_STAMPS
   unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t_last = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef MCL_COUNTS
+  unsigned long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
   int64_t p = (int64_t)blockIdx.x * kWavesPerBlock + wv;
@@ -176,7 +190,9 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
       const double oy = (double)((float)row * P.res_yf);
       const double dx = ox - x, dy = oy - y;              // :124-125, float64
       const double r2 = dx * dx + dy * dy;                // :126
+      COUNT(1);
       if (valid && r2 <= P.r2max) {       // :127
+        COUNTL(2);
         float af = atan2f((float)dy, (float)dx);
         if (af < 0.0f) af += 6.2831855f;
         const double aa = (double)af;
@@ -197,6 +213,7 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
         for (int c = c_lo; c <= c_hi; c += (seam ? 2 : 1)) {
           // window centre relative to the smallest table angle; small whenever the window can
           // hold a beam, so float32 is enough for everything but the edge cases
+          COUNT(3);
           const float centref = (float)(psi + (double)c * kTwoPi);
           const float lof = centref - reachf;
           int i0 = 0;
@@ -210,6 +227,8 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
           // before the first use, so their latency is paid once per group, not once per beam
 #pragma unroll 1
           for (int kb = i0; kb < NX; kb += kGroup) {
+            COUNT(4);
+            COUNTL(5);
             float eo[kGroup];
             unsigned long long rm[kGroup];
 #pragma unroll
@@ -225,11 +244,13 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
               const bool inside = ae <= sure_in, near = ae < sure_out;
               any_edge = any_edge | (live & (near != inside));   // too close to a sector edge for float32
               if (live & inside) {
+                COUNTL(7);
                 if (!STAGE || phase == 0) atomicMin(&rmin[kb + j], r2bits);
                 else atomicMin(&aux[kb + j], cellbits);       // lowest row-major index among equally near cells
               }
             }
             if (any_edge) {                                 // rare: exact float64 bearing
+              COUNT(6);
               if (!have_exact) {
                 // the empty asm pins the evaluation inside this branch (it must not be hoisted and
                 // run for every cell)
@@ -275,6 +296,7 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
       STAMP(2);
       for (unsigned int sb = 0; sb < n_cells; sb += 64) {
         const unsigned int e = e_next;
+        COUNT(0);
         if (sb + 64 + lane < n_cells) e_next = P.nbr_cells[first_cell + sb + 64 + lane];   // next batch in flight
         const float cdx = (float)(e & 0xffffu) * P.res_xf - xf;
         const float cdy = (float)(e >> 16) * P.res_yf - yf;
@@ -334,14 +356,29 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
       // partial product (sum of logs == log of product; 16 factors >= 1e-3 cannot underflow)
       double ls = 0.0, prod = 1.0;
       int nfac = 0;
+      // float64 state: the library logarithm.  float32 state: exponent and mantissa are split in
+      // integer arithmetic, the mantissa (in [1, 2)) goes through v_log_f32 and the two parts are
+      // joined in float64 -- absolute error ~1e-7 per call whatever the size of the product
+      auto log_of_product = [&](double v) -> double {
+        if constexpr (sizeof(R) == 4) {
+          const long long bits = __double_as_longlong(v);
+          const int ex = (int)((bits >> 52) & 0x7ff);
+          if (ex == 0 || ex == 0x7ff || bits < 0) return log(v);   // zero, subnormal, infinite, NaN, negative
+          const double mant = __longlong_as_double((bits & 0x000fffffffffffffll) | 0x3ff0000000000000ll);
+          return ((double)(ex - 1023) + (double)__builtin_amdgcn_logf((float)mant)) * 0.6931471805599453;
+        } else {
+          return log(v);
+        }
+      };
       for (int k = lane; k < B; k += 64) {
         const double r2 = __longlong_as_double((long long)rmin[G + k]);
         double zd;
         if constexpr (sizeof(R) == 4) {
-          // float32 square root refined by one Newton step in float64 (relative error ~1e-14)
-          const float z0 = sqrtf((float)r2);
+          // float32 square root refined by one Newton step in float64 (relative error ~1e-14);
+          // r2 <= z_max^2 holds for every entry, so the root is capped at z_max
+          const float z0 = __builtin_amdgcn_sqrtf((float)r2);
           const double z0d = (double)z0;
-          zd = (r2 > 0.0) ? z0d + (r2 - z0d * z0d) * (double)(0.5f / z0) : 0.0;
+          zd = (r2 > 0.0) ? fmin(z0d + (r2 - z0d * z0d) * (double)(0.5f * __builtin_amdgcn_rcpf(z0)), P.z_max) : 0.0;
         } else {
           zd = sqrt(r2);
         }
@@ -359,8 +396,10 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
           // float32 mode: the two exponentials in float32, exponents and the mixture itself in
           // float64 (float32 constants would bias every beam's log the same way)
           const double d = zd - ztd;
-          const float e_hit = exp((float)((d * d) * neg_half_inv_s2));
-          const float e_short = exp((float)(-P.lambda * zd));
+          // v_exp_f32 on the exponent scaled to base 2 (about 1e-7 relative; underflow to zero is what
+          // the mixture's constant floor absorbs)
+          const float e_hit = __builtin_amdgcn_exp2f((float)((d * d) * neg_half_inv_s2_log2e));
+          const float e_short = __builtin_amdgcn_exp2f((float)(neg_lambda_log2e * zd));
           pkd = (in_range ? (double)e_hit * (P.c_hit * P.w_hit) : 0.0) +
                 (in_short ? (double)e_short * (s_el[k] * P.w_short) : 0.0) +
                 ((fabs(zd - P.z_max) < 1e-6) ? P.w_max : 0.0) + (in_range ? P.p_rand * P.w_rand : 0.0);
@@ -375,13 +414,13 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
         }
         prod *= pkd;
         if (++nfac == 16) {
-          ls += log(prod);
+          ls += log_of_product(prod);
           prod = 1.0;
           nfac = 0;
         }
         if (PRODUCT) aux[s_perm[k]] = (unsigned long long)__double_as_longlong(pkd);
       }
-      if (nfac) ls += log(prod);
+      if (nfac) ls += log_of_product(prod);
       const double lsd = wave_sum(ls);
       double q = 1.0;
       if (PRODUCT) {
@@ -402,6 +441,10 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
 #ifdef MCL_STAMPS
   if (lane == 0)
     for (int i = 0; i < 8; ++i) atomicAdd(&P.stamps[i], acc[i]);
+#endif
+#ifdef MCL_COUNTS
+  for (int i = 0; i < 8; ++i)
+    if (cnt[i]) atomicAdd(&P.stamps[8 + i], cnt[i]);
 #endif
 }
 

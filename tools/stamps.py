@@ -15,9 +15,16 @@ X = W.uniform_particles(grid, M)
 ctx.set_particles(X)
 z = ctx.raycast(advance_true_pose(X[0].copy(), (1.5, 0.0), 0.1), want_hits=False)[0][0]
 base = [ctx.timing_get(100 + i)[0] for i in range(8)]
+base8 = [ctx.timing_get(108 + i)[0] for i in range(8)]
 ctx.step(1.5, 0.0, 0.1, [4, 2, 4, 4, 4, 2], z, 0.3 / M, None, 7, _lib.W_LOG, wait=True)
 now = [ctx.timing_get(100 + i)[0] for i in range(8)]
 d = np.array(now, float) - np.array(base, float)
 names = ["setup", "tile lists+scan", "fetch", "prefilter+ring", "match: geometry/bearing/window", "match: beam groups", "likelihood+store", "loop top (stamp overhead)"]
 for n, v in zip(names, d):
     print("%-34s %6.1f %%   %8.0f cycles/particle" % (n, 100 * v / d.sum(), v / M))
+
+cn = ["batches (wave)", "match calls (wave)", "cells within z_max (lane)", "window passes (wave)", "group steps (wave)",
+      "group steps (lane)", "edge branches (wave)", "minimum updates (lane)"]
+c = np.array([ctx.timing_get(108 + i)[0] for i in range(8)], float) - np.array(base8, float)
+for n, v in zip(cn, c):
+    print("%-34s %10.3f per particle" % (n, v / M))
