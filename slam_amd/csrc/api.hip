@@ -46,7 +46,6 @@ RayParams make_ray_params(const mclhip_ctx* c) {
   P.lambda = c->lambda;
   P.w_hit = c->w4[0]; P.w_short = c->w4[1]; P.w_max = c->w4[2]; P.w_rand = c->w4[3];
   P.p_rand = 1 / c->z_max;                               // range_sensor.py:64
-  { const char* d = getenv("MCLHIP_ABLATE"); P.dbg = d ? atoi(d) : 0; }
   P.range_noise = nullptr;
   P.stamps = c->stamps;
   P.no_obstacles = c->n_obstacles == 0 ? 1 : 0;

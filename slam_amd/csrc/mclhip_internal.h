@@ -51,7 +51,6 @@ struct RayParams {
   double lambda;
   double w_hit, w_short, w_max, w_rand;
   double p_rand;         // 1/z_max
-  int dbg;               // profiling ablations (0 in production)
   const double* range_noise;  // [n][B] additive noise on the predicted ranges, caller beam order (augmented MCL) or null
   int no_obstacles;      // the map holds no obstacle cell
   unsigned long long* stamps;  // profiling build only: cycles per kernel section

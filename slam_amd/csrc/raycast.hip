@@ -7,21 +7,25 @@
 // beta_k = deg_k*pi/180 + theta (never wrapped), then z_k = sqrt(min r2) and the
 // weight prod_k p(z_k | z*_k) * pm.
 //
-// How.  The map is held as per-tile obstacle lists (8x8-cell tiles; tile t owns
-// cells[tile_off[t] .. tile_off[t+1]), each entry (row << 16 | col)).  The wave
-// visits the tiles around the particle nearest-first (a host-built ring table,
-// two tiles per lane per pass), prefix-sums their list lengths across the lanes
-// and then walks the concatenated lists 64 cells at a time: lane j of a batch
-// finds its tile by a binary search over the prefix sums in LDS and loads its
-// cell.  Per cell: exact float64 dx, dy, r2; a float32 bearing selects the beams
-// whose sector the cell can fall into (eight beams per step, all their LDS reads
-// issued together); a cell that is not closer than a beam's current minimum is
-// dropped before any angle test; only where the float32 bearing is within
-// 1e-5 rad of a sector edge is the float64 atan2 evaluated.  Each (cell, beam)
+// How.  For every 8x8-cell tile the library keeps the "neighbourhood list": the
+// obstacle cells (row << 16 | col) of all tiles that can hold a cell within z_max
+// of some point of that tile, nearest tile first, contiguous in memory.  A wave
+// reads the slice of its particle's tile 64 cells at a time (next batch in
+// flight), drops cells outside the disk with a float32 test and queues the rest
+// in a 128-entry LDS ring; whenever 64 are queued they are matched together, so
+// the expensive part runs with (almost) all lanes busy.  Per matched cell:
+// exact float64 dx, dy, r2; a float32 bearing picks the window of the sorted
+// beam table the cell can fall into (the table is extended by images of the
+// top beams shifted by -2pi, so one window also covers the seam); the window's
+// eight entries are read from LDS together; a cell that is not closer than an
+// entry's current minimum is dropped before any angle test; only where the
+// float32 bearing is within 1e-5 rad of a sector edge is the float64 atan2
+// evaluated and the reference predicate applied literally.  Each (cell, beam)
 // match is a 64-bit LDS atomic min on the bit pattern of r2 (non-negative
-// doubles order like unsigned integers).  The beam table (sorted angles, bucket
-// index, measured ranges, short-reading constants) and the ring table are
-// staged in LDS once per block.
+// doubles order like unsigned integers).  The beam tables are staged in LDS
+// once per block.  The kernel is VALU-bound (about 75 % VALU-busy at three
+// waves per SIMD); its HBM traffic is the neighbourhood slices, ~1.4 KB per
+// particle.
 //
 // Compiled with -ffp-contract=off.
 #include <cstdlib>
