@@ -223,11 +223,51 @@ int mclhip_shard_pack(mclhip_ctx* ctx, const int64_t* lo, const int64_t* hi, int
 int mclhip_shard_unpack_resample(mclhip_ctx* ctx, const void* rows, int64_t L, double r, int64_t row0_global,
                                  int64_t* idx_out);
 
+/* Grid (histogram) localisation -- robot.py / grid_localization.py (Table 8.1) --
+ * on the same context.  The belief lives on the device as float32 [H][W][D]
+ * (the reference keeps float32, robot.py:49-60), the prediction as float64. */
+
+/* Replaces Robot.__init__'s map handling and make_obstacle_lut (robot.py:40-60,
+ * :195-205): cells with map < obstacle_below are obstacles, cells with
+ * map >= obstacle_below are free (robot.py:20, :157, :199 use 200); the initial
+ * belief is supported on cells with map != 0 (robot.py:53). */
+int mclhip_grid_set_map(mclhip_ctx* ctx, const uint8_t* map, int H, int W, double res_x, double res_y,
+                        int obstacle_below);
+
+/* Replaces the sensor set-up of Robot.__init__ (robot.py:28-36) for n_dir
+ * headings of res_theta_deg degrees (robot.py:8, :43): beam k of heading d points
+ * along angles_deg[k]*pi/180 + d*res_theta_deg*pi/180 (robot.py:252, :289).
+ * n_dir * B0 <= 1024.  Allocates the belief (zero). */
+int mclhip_grid_set_sensor(mclhip_ctx* ctx, const double* angles_deg, int B0, int n_dir, double res_theta_deg,
+                           double z_max, double sigma_hit, double lambda_short, const double w4[4],
+                           double sector_half_angle);
+
+/* Uniform belief over the cells with map != 0 (robot.py:49-60). */
+int mclhip_grid_init_belief(mclhip_ctx* ctx);
+/* Host <-> device copies of the belief [H][W][D] float32 and the prediction
+ * [H][W][D] float64 (either output pointer may be NULL). */
+int mclhip_grid_set_belief(mclhip_ctx* ctx, const float* pk);
+int mclhip_grid_set_prediction(mclhip_ctx* ctx, const double* pk_pred);
+int mclhip_grid_get_belief(mclhip_ctx* ctx, float* pk, double* pk_pred);
+
+/* Replaces the belief part of Robot.predict (robot.py:148-187): pk_pred =
+ * 7x7xD neighbourhood sum of pk * motion_model_velocity (robot.py:76-122) on
+ * interior free cells, 0 elsewhere.  All D headings are neighbours (the
+ * reference hard-codes its four, robot.py:168). */
+int mclhip_grid_predict(mclhip_ctx* ctx, double v, double omega, double dt, const double alpha[6]);
+
+/* Replaces Robot.update (robot.py:277-310) given the measured ranges
+ * z_meas[B0]: pk = float32(pk_pred * prod_k compute_px(z_meas[k], z_pred[k]))
+ * on free cells, 0 elsewhere, then pk /= pk.sum() in float32.  sum_out
+ * (nullable) receives that float32 sum. */
+int mclhip_grid_update(mclhip_ctx* ctx, const double* z_meas, float* sum_out);
+
 /* Measurement ------------------------------------------------------------ */
 
 /* Per-kernel timing with HIP events on the context's own stream.
  * which: 0 = sector-query + likelihood kernel, 1 = motion kernel,
- *        2 = normalise + resample + gather kernels together.
+ *        2 = normalise + resample + gather kernels together,
+ *        3 = grid prediction, 4 = grid update.
  * Enabling resets the accumulators. */
 int mclhip_timing_enable(mclhip_ctx* ctx, int on);
 int mclhip_timing_get(mclhip_ctx* ctx, int which, int64_t* launches, double* total_ms);

@@ -23,6 +23,7 @@ _i16_p = C.POINTER(C.c_int16)
 _i32_p = C.POINTER(C.c_int32)
 _i64_p = C.POINTER(C.c_int64)
 _u8_p = C.POINTER(C.c_uint8)
+_f32_p = C.POINTER(C.c_float)
 _ctx_p = C.c_void_p
 
 # name -> (restype, argtypes); every symbol include/mclhip.h declares
@@ -65,6 +66,15 @@ PROTOTYPES = {
     "mclhip_shard_count_below": (C.c_int, [_ctx_p, _dbl_p, C.c_int, _i64_p]),
     "mclhip_shard_pack": (C.c_int, [_ctx_p, _i64_p, _i64_p, C.c_int, C.c_void_p]),
     "mclhip_shard_unpack_resample": (C.c_int, [_ctx_p, C.c_void_p, C.c_int64, C.c_double, C.c_int64, _i64_p]),
+    "mclhip_grid_set_map": (C.c_int, [_ctx_p, _u8_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]),
+    "mclhip_grid_set_sensor": (C.c_int, [_ctx_p, _dbl_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                         C.c_double, _dbl_p, C.c_double]),
+    "mclhip_grid_init_belief": (C.c_int, [_ctx_p]),
+    "mclhip_grid_set_belief": (C.c_int, [_ctx_p, _f32_p]),
+    "mclhip_grid_set_prediction": (C.c_int, [_ctx_p, _dbl_p]),
+    "mclhip_grid_get_belief": (C.c_int, [_ctx_p, _f32_p, _dbl_p]),
+    "mclhip_grid_predict": (C.c_int, [_ctx_p, C.c_double, C.c_double, C.c_double, _dbl_p]),
+    "mclhip_grid_update": (C.c_int, [_ctx_p, _dbl_p, _f32_p]),
     "mclhip_timing_enable": (C.c_int, [_ctx_p, C.c_int]),
     "mclhip_timing_get": (C.c_int, [_ctx_p, C.c_int, _i64_p, _dbl_p]),
 }
@@ -334,6 +344,57 @@ class Context:
                                                        int(row0_global), _p(idx, _i64_p)),
                  "mclhip_shard_unpack_resample")
         return idx
+
+    # grid (histogram) localisation ------------------------------------------
+    def grid_set_map(self, grid, res_x, res_y, obstacle_below=200):
+        g = np.ascontiguousarray(grid, dtype=np.uint8)
+        if g.ndim != 2:
+            raise ValueError("map must be 2-D")
+        self._ck(self.lib.mclhip_grid_set_map(self.h, _p(g, _u8_p), g.shape[0], g.shape[1], float(res_x), float(res_y),
+                                              int(obstacle_below)), "mclhip_grid_set_map")
+        self.grid_shape = g.shape
+
+    def grid_set_sensor(self, angles_deg, n_dir, res_theta_deg, z_max, sigma_hit, lambda_short, w4, half_angle):
+        a = _f64(angles_deg)
+        w = _f64(w4, (4,))
+        self._ck(self.lib.mclhip_grid_set_sensor(self.h, _p(a, _dbl_p), len(a), int(n_dir), float(res_theta_deg),
+                                                 float(z_max), float(sigma_hit), float(lambda_short), _p(w, _dbl_p),
+                                                 float(half_angle)), "mclhip_grid_set_sensor")
+        self.grid_dirs = int(n_dir)
+        self.grid_beams = len(a)
+
+    def _grid_dims(self):
+        return (self.grid_shape[0], self.grid_shape[1], self.grid_dirs)
+
+    def grid_init_belief(self):
+        self._ck(self.lib.mclhip_grid_init_belief(self.h), "mclhip_grid_init_belief")
+
+    def grid_set_belief(self, pk):
+        a = np.ascontiguousarray(pk, dtype=np.float32)
+        if a.shape != self._grid_dims():
+            raise ValueError("belief must have shape %r" % (self._grid_dims(),))
+        self._ck(self.lib.mclhip_grid_set_belief(self.h, _p(a, _f32_p)), "mclhip_grid_set_belief")
+
+    def grid_set_prediction(self, pk_pred):
+        a = _f64(pk_pred, self._grid_dims())
+        self._ck(self.lib.mclhip_grid_set_prediction(self.h, _p(a, _dbl_p)), "mclhip_grid_set_prediction")
+
+    def grid_get_belief(self, want_pk=True, want_pred=False):
+        pk = np.empty(self._grid_dims(), np.float32) if want_pk else None
+        pp = np.empty(self._grid_dims(), np.float64) if want_pred else None
+        self._ck(self.lib.mclhip_grid_get_belief(self.h, _p(pk, _f32_p), _p(pp, _dbl_p)), "mclhip_grid_get_belief")
+        return pk, pp
+
+    def grid_predict(self, v, omega, dt, alpha):
+        al = _f64(alpha, (6,))
+        self._ck(self.lib.mclhip_grid_predict(self.h, float(v), float(omega), float(dt), _p(al, _dbl_p)),
+                 "mclhip_grid_predict")
+
+    def grid_update(self, z_meas):
+        z = _f64(z_meas, (self.grid_beams,))
+        s = C.c_float(0.0)
+        self._ck(self.lib.mclhip_grid_update(self.h, _p(z, _dbl_p), C.byref(s)), "mclhip_grid_update")
+        return np.float32(s.value)
 
     def timing_enable(self, on=True):
         self._ck(self.lib.mclhip_timing_enable(self.h, 1 if on else 0), "mclhip_timing_enable")

@@ -48,6 +48,7 @@ RayParams make_ray_params(const mclhip_ctx* c) {
   P.p_rand = 1 / c->z_max;                               // range_sensor.py:64
   P.range_noise = nullptr;
   P.stamps = c->stamps;
+  P.g_cell = nullptr; P.g_pk_pred = nullptr; P.g_pk = nullptr; P.g_D = 0; P.g_B0 = 0;
   P.no_obstacles = c->n_obstacles == 0 ? 1 : 0;
   return P;
 }
@@ -279,7 +280,7 @@ void mclhip_destroy(mclhip_ctx* c) {
                   c->px[0], c->px[1], c->py[0], c->py[1], c->pth[0], c->pth[1], c->w[0], c->w[1], c->logw, c->pm,
                   c->sx, c->sy, c->sth, c->sw, c->chunk_sums, c->scal, c->cdf_approx, c->cdf_exact, c->kscan,
                   c->fscan, c->blk_a, c->blk_b, c->irr, c->bases, c->idx, c->noise, c->counters, c->range_noise, c->inj_rows, c->stamps,
-                  c->inj_poses, c->g_records, c->g_bases,
+                  c->inj_poses, c->g_records, c->g_bases, c->gl_mask, c->gl_x, c->gl_y, c->gl_th, c->gl_cell, c->gl_pk, c->gl_pk_pred, c->gl_K, c->gl_part,
                   c->rows_send, c->rows_recv, c->small_d, c->small_i};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -339,14 +340,24 @@ int mclhip_set_sensor(mclhip_ctx* c, const double* angles_deg, int B, double z_m
   MCL_TRY(use(c));
   if (!angles_deg || !w4 || B <= 0) return fail(c, MCLHIP_E_ARG, "angles/w4 NULL or B <= 0");
   if (B > kMaxBeams) return fail(c, MCLHIP_E_LIMIT, "at most 1024 beams");
-  if (!(z_max > 0) || !(sigma_hit > 0) || !(half >= 0)) return fail(c, MCLHIP_E_ARG, "bad sensor constants");
   for (int k = 0; k < B; ++k)
     if (!std::isfinite(angles_deg[k])) return fail(c, MCLHIP_E_ARG, "beam angles must be finite");
+  std::vector<double> tab(B);
+  for (int k = 0; k < B; ++k) tab[k] = angles_deg[k] * M_PI / 180.0;  // angle*np.pi/180.0 (mc_localization.py:143)
+  return mcl::set_sensor_table(c, tab.data(), B, z_max, sigma_hit, lambda_short, w4, half);
+}
+
+}  // extern "C"
+
+// Beam table from angles in radians (the sector query adds the pose heading to them).
+int mcl::set_sensor_table(mclhip_ctx* c, const double* tab_rad, int B, double z_max, double sigma_hit,
+                          double lambda_short, const double w4[4], double half) {
+  if (B > kMaxBeams) return fail(c, MCLHIP_E_LIMIT, "at most 1024 beams");
+  if (!(z_max > 0) || !(sigma_hit > 0) || !(half >= 0)) return fail(c, MCLHIP_E_ARG, "bad sensor constants");
   c->B = B; c->z_max = z_max; c->sigma = sigma_hit; c->lambda = lambda_short; c->half = half;
   c->ring_dirty = true;
   for (int i = 0; i < 4; ++i) c->w4[i] = w4[i];
-  std::vector<double> tab(B), ts(B);
-  for (int k = 0; k < B; ++k) tab[k] = angles_deg[k] * M_PI / 180.0;  // angle*np.pi/180.0 (mc_localization.py:143)
+  std::vector<double> tab(tab_rad, tab_rad + B), ts(B);
   std::vector<uint16_t> perm(B);
   std::iota(perm.begin(), perm.end(), 0);
   std::stable_sort(perm.begin(), perm.end(), [&](uint16_t a, uint16_t b) { return tab[a] < tab[b]; });
@@ -360,8 +371,9 @@ int mclhip_set_sensor(mclhip_ctx* c, const double* angles_deg, int B, double z_m
   const double two_pi = M_PI * 2;
   std::vector<float> relx;
   int G = 0;
-  for (int k = 0; k < B; ++k)
-    if (ts[k] - c->ts_min >= two_pi - 2.0 * reach - 1e-6) ++G;
+  if (span < two_pi - 1e-9)   // a table that spans a full turn or more is matched window by window, without images
+    for (int k = 0; k < B; ++k)
+      if (ts[k] - c->ts_min >= two_pi - 2.0 * reach - 1e-6) ++G;
   if (G > B - 1) G = B > 1 ? B - 1 : 0;   // never an image of every beam
   if (G > 64) return fail(c, MCLHIP_E_LIMIT, "more than 64 beams within one sector width of the 0/2pi seam");
   for (int k = B - G; k < B; ++k) relx.push_back((float)((ts[k] - c->ts_min) - two_pi));
@@ -396,6 +408,8 @@ int mclhip_set_sensor(mclhip_ctx* c, const double* angles_deg, int B, double z_m
   MCL_HIP(c, hipMemset(c->etalam, 0, B * sizeof(double)));
   return MCLHIP_OK;
 }
+
+extern "C" {
 
 int mclhip_set_particles(mclhip_ctx* c, const double* X, const double* w, int64_t M) {
   MCL_TRY(use(c));
@@ -860,7 +874,7 @@ int mclhip_shard_unpack_resample(mclhip_ctx* c, const void* rows, int64_t L, dou
 int mclhip_timing_enable(mclhip_ctx* c, int on) {
   if (!c) return MCLHIP_E_ARG;
   c->timing = on != 0;
-  for (int i = 0; i < 3; ++i) { c->t_launch[i] = 0; c->t_ms[i] = 0; }
+  for (int i = 0; i < 5; ++i) { c->t_launch[i] = 0; c->t_ms[i] = 0; }
   return MCLHIP_OK;
 }
 
@@ -872,7 +886,7 @@ int mclhip_timing_get(mclhip_ctx* c, int which, int64_t* launches, double* total
     if (total_ms) *total_ms = (double)v;
     return MCLHIP_OK;
   }
-  if (!c || which < 0 || which > 2) return MCLHIP_E_ARG;
+  if (!c || which < 0 || which > 4) return MCLHIP_E_ARG;
   if (launches) *launches = c->t_launch[which];
   if (total_ms) *total_ms = c->t_ms[which];
   return MCLHIP_OK;

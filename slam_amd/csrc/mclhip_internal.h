@@ -54,6 +54,11 @@ struct RayParams {
   const double* range_noise;  // [n][B] additive noise on the predicted ranges, caller beam order (augmented MCL) or null
   int no_obstacles;      // the map holds no obstacle cell
   unsigned long long* stamps;  // profiling build only: cycles per kernel section
+  // histogram-filter update (one pose per free grid cell)
+  const int32_t* g_cell;       // flat cell index of pose p
+  const double* g_pk_pred;     // [H*W*D]
+  float* g_pk;                 // [H*W*D]
+  int g_D, g_B0;               // headings, beams per heading
 };
 
 struct MotionParams {
@@ -145,10 +150,24 @@ struct mclhip_ctx {
   void* rows_recv = nullptr; int64_t rows_recv_cap = 0;
   double* small_d = nullptr; int64_t* small_i = nullptr;  // [1024] staging for boundary queries
 
+  // histogram filter (grid localisation): belief over (row, col, heading)
+  int gl_D = 0, gl_B0 = 0;          // headings, beams per heading
+  double gl_res_theta = 0;          // degrees per heading bin
+  int64_t gl_nfree = 0;             // cells at or above the obstacle threshold
+  int64_t gl_nprior = 0;            // cells with a non-zero map value (support of the initial belief)
+  uint8_t* gl_mask = nullptr;       // [H*W] 1 where the cell is free, 2 where only the raw map value is non-zero
+  double* gl_x = nullptr; double* gl_y = nullptr; double* gl_th = nullptr;   // poses of the free cells
+  int32_t* gl_cell = nullptr;       // their flat indices
+  float* gl_pk = nullptr;           // [H*W*D] belief, float32 as the reference keeps it
+  double* gl_pk_pred = nullptr;     // [H*W*D] prediction
+  double* gl_K = nullptr;           // motion-model coefficients of the current control
+  float* gl_part = nullptr;         // float32 chunk sums + total
+  std::vector<double> gl_angles_deg;
+
   // timing
   bool timing = false;
-  int64_t t_launch[3] = {0, 0, 0};
-  double t_ms[3] = {0, 0, 0};
+  int64_t t_launch[5] = {0, 0, 0, 0, 0};
+  double t_ms[5] = {0, 0, 0, 0, 0};
   struct Span { hipEvent_t a, b; int which; };
   std::vector<Span> spans;   // event pairs recorded but not yet read back
 };
@@ -167,6 +186,10 @@ int fail(mclhip_ctx* c, int code, const std::string& msg);
 // kernels launchers, one per stage; all enqueue on c->stream
 int launch_build_tiles(mclhip_ctx* c, const uint8_t* d_map);
 int launch_beam_table(mclhip_ctx* c);
+int set_sensor_table(mclhip_ctx* c, const double* tab_rad, int B, double z_max, double sigma_hit, double lambda_short,
+                     const double w4[4], double half);
+int launch_grid_update(mclhip_ctx* c, const double* d_x, const double* d_y, const double* d_th, const int32_t* d_cell,
+                       int64_t n, int n_dir, int beams_per_dir, const double* pk_pred, float* pk);
 int build_ring_table(mclhip_ctx* c);
 int launch_nbr_count(mclhip_ctx* c, uint32_t* d_cnt);
 int launch_nbr_fill(mclhip_ctx* c);

@@ -92,7 +92,7 @@ __device__ inline double wave_sum(double v) {
 #ifndef MCL_RAY_WAVES
 #define MCL_RAY_WAVES 3
 #endif
-template <typename T, bool STAGE, bool PRODUCT>
+template <typename T, bool STAGE, bool PRODUCT, bool GRID = false>
 __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
     RayParams P, const T* __restrict__ xs, const T* __restrict__ ys, const T* __restrict__ ths,
     const uint8_t* __restrict__ pm, int64_t n, double* __restrict__ w_out, double* __restrict__ logw_out,
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
   unsigned long long* s_rmin_all = reinterpret_cast<unsigned long long*>(s_el + B);
   const int NXP = P.G + B + kGroup;                              // extended table + one group of padding
   unsigned long long* s_aux_all = s_rmin_all + (size_t)kWavesPerBlock * NXP;
-  unsigned int* s_walk_all = reinterpret_cast<unsigned int*>(s_aux_all + (size_t)((STAGE || PRODUCT) ? kWavesPerBlock * NXP : 0));
+  unsigned int* s_walk_all = reinterpret_cast<unsigned int*>(s_aux_all + (size_t)((STAGE || PRODUCT || GRID) ? kWavesPerBlock * NXP : 0));
   float* s_relx = reinterpret_cast<float*>(s_walk_all + (size_t)kWavesPerBlock * kWaveScratch);  // [G + B] extended angle table
   unsigned short* s_perm = reinterpret_cast<unsigned short*>(s_relx + NXP);
   unsigned short* s_lut = s_perm + B;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
     s_perm[k] = P.perm[k];
     if (!STAGE) {
       s_zt[k] = P.zt[k];
-      s_el[k] = P.etalam[k];
+      if (!GRID) s_el[k] = P.etalam[k];
     }
   }
   for (int k = threadIdx.x; k < NXP; k += blockDim.x) s_relx[k] = (k < P.G + B) ? P.relx[k] : 1.0e30f;  // padding: beyond any window
@@ -155,14 +155,14 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
   int64_t p = (int64_t)blockIdx.x * kWavesPerBlock + wv;
   T nx = (T)0, ny = (T)0, nth = (T)0;
   unsigned char npm = 0;
-  if (p < n) { nx = xs[p]; ny = ys[p]; nth = ths[p]; if (!STAGE) npm = pm[p]; }
+  if (p < n) { nx = xs[p]; ny = ys[p]; nth = ths[p]; if (!STAGE && !GRID) npm = pm[p]; }
   for (; p < n; p += stride) {
     STAMP(7);
     const double x = (double)nx, y = (double)ny, th = (double)nth;
     const bool on_free = npm != 0;
     if (p + stride < n) {   // next pose in flight
       nx = xs[p + stride]; ny = ys[p + stride]; nth = ths[p + stride];
-      if (!STAGE) npm = pm[p + stride];
+      if (!STAGE && !GRID) npm = pm[p + stride];
     }
     for (int k = lane; k < NXP; k += 64) {
       rmin[k] = r2max_bits;
@@ -354,6 +354,33 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
         const unsigned int h = (unsigned int)aux[G + k];
         hits_out[p * B + ko] = (h == 0xffffffffu) ? -1 : (int32_t)h;
       }
+    } else if (GRID) {
+      // Histogram filter (robot.py:289-300): the pose is a grid cell, the beam table holds every
+      // (heading, beam) pair of that cell, and the measured range is the FIRST argument of
+      // compute_px here (range_sensor.py:95-112 called from robot.py:297), the predicted one the second.
+      for (int k = lane; k < B; k += 64) {
+        const double z = sqrt(__longlong_as_double((long long)rmin[G + k]));   // robot.py:269
+        const double xm = s_zt[k];
+        const bool in_range = (0.0 <= xm) && (xm <= P.z_max);
+        const double d = xm - z;
+        const double p_hit = in_range ? P.c_hit * exp(-0.5 * (d * d) / P.sigma2) : 0.0;
+        double p_short = 0.0;
+        if ((0.0 <= xm) && (xm <= z)) {
+          const double eta = 1.0 / (1.0 - exp(-P.lambda * z));
+          p_short = eta * P.lambda * exp(-P.lambda * xm);
+        }
+        const double p_max = (fabs(xm - P.z_max) < 1e-6) ? 1.0 : 0.0;
+        const double p_rand = in_range ? P.p_rand : 0.0;
+        const double pkd = p_hit * P.w_hit + p_short * P.w_short + p_max * P.w_max + p_rand * P.w_rand;
+        aux[s_perm[k]] = (unsigned long long)__double_as_longlong(pkd);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      const int64_t cell = P.g_cell[p];
+      for (int d = lane; d < P.g_D; d += 64) {
+        double q = 1.0;   // q *= p_k in beam order (robot.py:295-298)
+        for (int k = 0; k < P.g_B0; ++k) q = q * __longlong_as_double((long long)aux[d * P.g_B0 + k]);
+        P.g_pk[cell * P.g_D + d] = (float)(P.g_pk_pred[cell * P.g_D + d] * q);   // robot.py:300, float32 store
+      }
     } else {
       typedef T R;  // likelihood arithmetic follows the state dtype
       // log-weight: each lane multiplies its few p_k in float64 and takes one logarithm of the
@@ -461,6 +488,26 @@ static size_t ray_lds_bytes(int B, int G, int NB, int n_ring, bool aux) {
   s += ((size_t)B + NB + 2) * sizeof(unsigned short);
   (void)n_ring;
   return (s + 15) & ~(size_t)15;
+}
+
+// Measurement update of the histogram filter: one wave per free cell, beam table = all (heading,
+// beam) pairs.  d_x/d_y/d_th: float64 poses of the free cells (th = 0), d_cell their flat index.
+int launch_grid_update(mclhip_ctx* c, const double* d_x, const double* d_y, const double* d_th, const int32_t* d_cell,
+                       int64_t n, int n_dir, int beams_per_dir, const double* pk_pred, float* pk) {
+  if (n <= 0) return MCLHIP_OK;
+  RayParams P = make_ray_params(c);
+  P.g_cell = d_cell; P.g_D = n_dir; P.g_B0 = beams_per_dir; P.g_pk_pred = pk_pred; P.g_pk = pk;
+  const size_t lds = ray_lds_bytes(P.B, P.G, P.NB, P.n_ring, true);
+  if (lds > 160 * 1024) return fail(c, MCLHIP_E_LIMIT, "heading x beam table does not fit the kernel's LDS budget");
+  auto kern = raycast_kernel<double, false, false, true>;
+  if (lds > 48 * 1024)
+    MCL_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int64_t blocks = (n + kWavesPerBlock - 1) / kWavesPerBlock;
+  if (blocks > 256 * 8 * 4) blocks = 256 * 8 * 4;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, c->stream, P, d_x, d_y, d_th,
+                     (const uint8_t*)nullptr, n, (double*)nullptr, (double*)nullptr, (double*)nullptr, (int32_t*)nullptr);
+  MCL_HIP(c, hipGetLastError());
+  return MCLHIP_OK;
 }
 
 int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, const uint8_t* pm, int64_t n,

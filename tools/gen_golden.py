@@ -495,11 +495,63 @@ def case_amcl():
                                                "x0": x0, "seed": np.array(seed)})
 
 
+def case_grid():
+    """Grid localisation (robot.py / grid_localization.py): the reference's Robot on its own
+    grid_map0.png, predict() + update() under a seeded np.random, every stage captured."""
+    im = Image.open(os.path.join(REF, "grid_map0.png")).convert("RGB")
+    grid = np.ascontiguousarray(np.array(im)[:, :, 2])      # cv2.imread(...)[:, :, 0] is the blue channel
+    for name, seed, controls in (("grid_seed0", 0, [(1.5, 0), (1.5, 0)]), ("grid_seed1", 1, [(1.5, 0.5)])):
+        np.random.seed(seed)
+        x_pose = np.array([[20 * ref_robot.res_x, 30 * ref_robot.res_y, 0]], dtype=np.float32).T
+        with contextlib.redirect_stdout(io.StringIO()):
+            robot = ref_robot.Robot(grid, x_pose)
+        out = {"map": grid, "sensor_angles": np.array(robot.sensor_angles, np.float64), "seed": np.array(seed),
+               "pk0": robot.pk.copy(), "n_steps": np.array(len(controls))}
+        for t, ut in enumerate(controls):
+            draws = []
+            first = []
+            orig_random = np.random.random
+            orig_pm = ref_robot.Robot.predict_measure
+
+            def spy_random(*a, **k):
+                v = orig_random(*a, **k)
+                draws.append(v)
+                return v
+
+            def spy_pm(self, xt, map):
+                r = orig_pm(self, xt, map)
+                if not first:
+                    first.append([np.float64(v) for v in r])
+                return r
+
+            pre = {"pk_in": robot.pk.copy(), "x_gt_in": robot.x_gt.copy()}
+            with contextlib.redirect_stdout(io.StringIO()):
+                robot.predict(list(ut))
+                np.random.random = spy_random
+                ref_robot.Robot.predict_measure = spy_pm
+                try:
+                    pk_pred = robot.pk_pred.copy()
+                    robot.update()
+                finally:
+                    np.random.random = orig_random
+                    ref_robot.Robot.predict_measure = orig_pm
+            rec = dict(pre)
+            rec.update({"ut": np.array(ut, np.float64), "x_gt_out": robot.x_gt.copy(), "pk_pred": pk_pred,
+                        "uniforms": np.array(draws), "z_true": np.array(first[0]),
+                        "z_meas": np.array([float(v) for v in robot.sensor_ranges]), "pk_out": robot.pk.copy()})
+            for k, v in rec.items():
+                out["s%d_%s" % (t, k)] = v
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+        print("wrote", name, "steps", len(controls), "pk max", float(robot.pk.max()), "dtype", robot.pk.dtype)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["demo", "robot", "px", "resample", "motion", "synth", "amcl"]
+    which = sys.argv[1:] or ["demo", "robot", "px", "resample", "motion", "synth", "amcl", "grid"]
     if "amcl" in which:
         case_amcl()
+    if "grid" in which:
+        case_grid()
     if "demo" in which:
         case_reference_demo()
     if "robot" in which:
