@@ -180,7 +180,15 @@ __global__ __launch_bounds__(512) void chunk_sum_f32_kernel(const float* __restr
 __global__ void total_sum_f32_kernel(const float* __restrict__ chunk_sums, int64_t nchunks, float* __restrict__ total) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   float t = chunk_sums[0];
-  for (int64_t i = 1; i < nchunks; ++i) t = t + chunk_sums[i];
+  int64_t i = 1;
+  for (; i + 16 <= nchunks; i += 16) {   // loads issued together, additions strictly left to right
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = chunk_sums[i + j];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t = t + v[j];
+  }
+  for (; i < nchunks; ++i) t = t + chunk_sums[i];
   total[0] = t;
 }
 
