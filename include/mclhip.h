@@ -262,6 +262,38 @@ int mclhip_grid_predict(mclhip_ctx* ctx, double v, double omega, double dt, cons
  * (nullable) receives that float32 sum. */
 int mclhip_grid_update(mclhip_ctx* ctx, const double* z_meas, float* sum_out);
 
+/* FastSLAM 1.0 with unknown correspondence -- 13_fast_slam/fast_slam1.py -- on a
+ * float64 context.  Particle poses and weights share the particle-filter state
+ * (mclhip_get_particles); landmark features live in `capacity` slots per particle. */
+
+/* Replaces FastSLAM.__init__ (fast_slam1.py:98-108): M particles at the origin,
+ * no features. */
+int mclhip_fs_init(mclhip_ctx* ctx, int64_t M, int capacity);
+
+/* Module constants of fast_slam1.py:27-39 (STD_R, STD_PHI, r_max, P0, thres_sig);
+ * the defaults are the reference's values. */
+int mclhip_fs_set_model(mclhip_ctx* ctx, double std_r, double std_phi, double r_max, double p0, double thres_sig);
+
+/* Replaces FastSLAM.fast_slam (fast_slam1.py:240-433) without the plotting.
+ * truth_r/truth_phi/truth_valid [L]: range and bearing of every landmark from the
+ * TRUE pose before noise and whether it is sensed (measure(), :131-142); each
+ * particle adds its own noise to them (:145-146 inside the particle loop, :288).
+ * ints [M][3][12] int16: the integers of the pose sampler (:163), NULL = device
+ * generator.  normals [M][2 * #valid]: the standard normals of the measurements
+ * in consumption order, NULL = device generator keyed by `seed`.
+ * r = np.random.rand() * 1/M (:423).  idx_out [M] nullable: ancestor indices.
+ * Returns MCLHIP_E_LIMIT when a particle needs more feature slots than capacity. */
+int mclhip_fs_step(mclhip_ctx* ctx, double v, double omega, double dt, const double alpha[6], const double* truth_r,
+                   const double* truth_phi, const uint8_t* truth_valid, int L, const int16_t* ints,
+                   const double* normals, uint64_t seed, double r, int64_t* idx_out);
+
+/* Particle and feature state, all pointers nullable: pose [M][3], w [M],
+ * nfeat [M], new_id [M] (Particle.new_feature_id), f_m [M][cap][2],
+ * f_cov [M][cap][2][2], f_i [M][cap] (observation counters), f_w [M][cap],
+ * f_id [M][cap]; unused slots read 0 (f_id: -1). */
+int mclhip_fs_get_state(mclhip_ctx* ctx, double* pose, double* w, int32_t* nfeat, int32_t* new_id, double* f_m,
+                        double* f_cov, int32_t* f_i, double* f_w, int32_t* f_id);
+
 /* Measurement ------------------------------------------------------------ */
 
 /* Per-kernel timing with HIP events on the context's own stream.

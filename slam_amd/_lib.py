@@ -75,6 +75,11 @@ PROTOTYPES = {
     "mclhip_grid_get_belief": (C.c_int, [_ctx_p, _f32_p, _dbl_p]),
     "mclhip_grid_predict": (C.c_int, [_ctx_p, C.c_double, C.c_double, C.c_double, _dbl_p]),
     "mclhip_grid_update": (C.c_int, [_ctx_p, _dbl_p, _f32_p]),
+    "mclhip_fs_init": (C.c_int, [_ctx_p, C.c_int64, C.c_int]),
+    "mclhip_fs_set_model": (C.c_int, [_ctx_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "mclhip_fs_step": (C.c_int, [_ctx_p, C.c_double, C.c_double, C.c_double, _dbl_p, _dbl_p, _dbl_p, _u8_p, C.c_int,
+                                 _i16_p, _dbl_p, C.c_uint64, C.c_double, _i64_p]),
+    "mclhip_fs_get_state": (C.c_int, [_ctx_p, _dbl_p, _dbl_p, _i32_p, _i32_p, _dbl_p, _dbl_p, _i32_p, _dbl_p, _i32_p]),
     "mclhip_timing_enable": (C.c_int, [_ctx_p, C.c_int]),
     "mclhip_timing_get": (C.c_int, [_ctx_p, C.c_int, _i64_p, _dbl_p]),
 }
@@ -395,6 +400,46 @@ class Context:
         s = C.c_float(0.0)
         self._ck(self.lib.mclhip_grid_update(self.h, _p(z, _dbl_p), C.byref(s)), "mclhip_grid_update")
         return np.float32(s.value)
+
+    # FastSLAM 1.0 ------------------------------------------------------------
+    def fs_init(self, M, capacity):
+        self._ck(self.lib.mclhip_fs_init(self.h, int(M), int(capacity)), "mclhip_fs_init")
+        self.fs_M, self.fs_cap = int(M), int(capacity)
+
+    def fs_set_model(self, std_r, std_phi, r_max, p0, thres_sig):
+        self._ck(self.lib.mclhip_fs_set_model(self.h, float(std_r), float(std_phi), float(r_max), float(p0),
+                                              float(thres_sig)), "mclhip_fs_set_model")
+
+    def fs_step(self, v, omega, dt, alpha, truth_r, truth_phi, truth_valid, ints, normals, r, seed=0, want_idx=False):
+        al = _f64(alpha, (6,))
+        tr_, tp = _f64(truth_r), _f64(truth_phi)
+        tv = np.ascontiguousarray(truth_valid, dtype=np.uint8)
+        L = len(tr_)
+        if tp.shape != (L,) or tv.shape != (L,):
+            raise ValueError("truth arrays must have one entry per landmark")
+        nv = int(np.count_nonzero(tv))
+        if ints is not None:
+            ints = np.ascontiguousarray(ints, dtype=np.int16)
+            if ints.shape != (self.fs_M, 3, 12):
+                raise ValueError("ints must have shape (M, 3, 12)")
+        if normals is not None:
+            normals = _f64(normals, (self.fs_M, 2 * nv))
+        idx = np.empty(self.fs_M, np.int64) if want_idx else None
+        self._ck(self.lib.mclhip_fs_step(self.h, float(v), float(omega), float(dt), _p(al, _dbl_p), _p(tr_, _dbl_p),
+                                         _p(tp, _dbl_p), _p(tv, _u8_p), L, _p(ints, _i16_p), _p(normals, _dbl_p),
+                                         int(seed), float(r), _p(idx, _i64_p)), "mclhip_fs_step")
+        return idx
+
+    def fs_get_state(self):
+        M, F = self.fs_M, self.fs_cap
+        out = {"pose": np.empty((M, 3)), "w": np.empty(M), "nfeat": np.empty(M, np.int32), "new_id": np.empty(M, np.int32),
+               "f_m": np.empty((M, F, 2)), "f_cov": np.empty((M, F, 2, 2)), "f_i": np.empty((M, F), np.int32),
+               "f_w": np.empty((M, F)), "f_id": np.empty((M, F), np.int32)}
+        self._ck(self.lib.mclhip_fs_get_state(self.h, _p(out["pose"], _dbl_p), _p(out["w"], _dbl_p),
+                                              _p(out["nfeat"], _i32_p), _p(out["new_id"], _i32_p),
+                                              _p(out["f_m"], _dbl_p), _p(out["f_cov"], _dbl_p), _p(out["f_i"], _i32_p),
+                                              _p(out["f_w"], _dbl_p), _p(out["f_id"], _i32_p)), "mclhip_fs_get_state")
+        return out
 
     def timing_enable(self, on=True):
         self._ck(self.lib.mclhip_timing_enable(self.h, 1 if on else 0), "mclhip_timing_enable")

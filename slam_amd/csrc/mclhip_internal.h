@@ -164,6 +164,8 @@ struct mclhip_ctx {
   float* gl_part = nullptr;         // float32 chunk sums + total
   std::vector<double> gl_angles_deg;
 
+  void* fs = nullptr;               // FastSLAM storage (fastslam.hip owns the type)
+
   // timing
   bool timing = false;
   int64_t t_launch[5] = {0, 0, 0, 0, 0};
@@ -199,6 +201,8 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
                    int dtype, double* w_out, double* logw_out, double* ranges_out, int32_t* hits_out,
                    const double* range_noise = nullptr);
 int launch_mean_weight(mclhip_ctx* c);
+int launch_sequential_total(mclhip_ctx* c);   // c->cdf_exact = strictly sequential running sum of the live weights
+void fs_release(mclhip_ctx* c);
 int launch_inject(mclhip_ctx* c, const int64_t* d_rows, const double* d_poses, int64_t n_inj, int which_buffer,
                   bool set_weight);
 int launch_compute_px(mclhip_ctx* c, const double* z, const double* zt, int64_t n, double* p);

@@ -647,6 +647,9 @@ int launch_mean_weight(mclhip_ctx* c) {
   return MCLHIP_OK;
 }
 
+// running sum of the live weights exactly as `s = 0; for w in weights: s += w` produces it
+int launch_sequential_total(mclhip_ctx* c) { return build_exact_cdf(c, c->w[c->cur], c->M); }
+
 template <typename T>
 __global__ void inject_kernel(const int64_t* __restrict__ rows, const double* __restrict__ poses, int64_t n_inj,
                               T* __restrict__ x, T* __restrict__ y, T* __restrict__ th, double* __restrict__ w,

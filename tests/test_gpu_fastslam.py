@@ -1,0 +1,112 @@
+"""FastSLAM 1.0 on the GPU (through the C ABI) against the state the reference's FastSLAM object
+reached under the same random numbers (tests/golden/fastslam_*.npz).  Needs an MI355X: `-m gpu`.
+
+Bars: ancestor indices, feature counts, feature ids and observation counters bit-exact at every
+step; poses, weights, feature means within 1e-12 relative; feature covariances within 1e-11 of
+the matrix's largest entry (the EKF update forms (I - K H) Cov, whose small entries are
+differences of products: an ulp of numpy's BLAS-ordered 2x2 products is not an ulp of the result).
+"""
+import numpy as np
+import pytest
+
+from oracle import fastslam_oracle as F
+from util import load, rel_err, steps
+
+pytestmark = pytest.mark.gpu
+
+
+def _truth(x_gt, landmarks):
+    t = F.true_measurements(list(x_gt), landmarks)
+    return np.array([float(a[0]) for a in t]), np.array([float(a[1]) for a in t]), np.array([a[2] for a in t], np.uint8)
+
+
+def _compare(st, s, t):
+    n = s["f_m"].shape[1]
+    assert np.array_equal(st["nfeat"], s["nfeat"]), t
+    assert np.array_equal(st["new_id"], s["new_id"]), t
+    assert np.array_equal(st["f_id"][:, :n], s["f_id"]), t
+    assert np.array_equal(st["f_i"][:, :n], s["f_i"]), t
+    assert rel_err(st["pose"], s["pose"]) < 1e-12, (t, rel_err(st["pose"], s["pose"]))
+    assert rel_err(st["w"], s["w"]) < 1e-12, (t, rel_err(st["w"], s["w"]))
+    assert rel_err(st["f_w"][:, :n], s["f_w"]) < 1e-11, (t, rel_err(st["f_w"][:, :n], s["f_w"]))
+    assert rel_err(st["f_m"][:, :n], s["f_m"]) < 1e-12, (t, rel_err(st["f_m"][:, :n], s["f_m"]))
+    scale = np.max(np.abs(s["f_cov"]), axis=(2, 3), keepdims=True)
+    err = np.abs(st["f_cov"][:, :n] - s["f_cov"])
+    assert np.all(err <= 1e-11 * scale), (t, float(np.max(err / np.maximum(scale, 1e-300))))
+
+
+@pytest.mark.parametrize("name", ["fastslam_seed0", "fastslam_seed3"])
+def test_follows_the_reference_step_by_step(name):
+    from slam_amd import _lib as L
+    g = load(name)
+    M = int(g["M"])
+    lm = g["landmarks"].astype(np.float32)
+    ctx = L.Context(0, L.F64)
+    ctx.fs_init(M, 16)
+    # independent chain: the device carries its own state from step to step
+    x_gt = [0, 0, 0]
+    for t, s in enumerate(steps(g)):
+        ut = [float(s["ut"][0]), float(s["ut"][1])]
+        x_gt = F.true_pose_step(x_gt, ut)
+        tr, tp, tv = _truth(x_gt, lm)
+        r = float(s["r_uniform"][0]) * 1 / M
+        idx = ctx.fs_step(ut[0], ut[1], F.DT, F.ALPHA, tr, tp, tv, s["ints"], s["normals"], r, want_idx=True)
+        _compare(ctx.fs_get_state(), s, t)
+
+
+def test_ancestors_equal_the_oracle_walk():
+    from slam_amd import _lib as L
+    g = load("fastslam_seed0")
+    M = int(g["M"])
+    lm = g["landmarks"].astype(np.float32)
+    ctx = L.Context(0, L.F64)
+    ctx.fs_init(M, 16)
+    orc = F.OracleFastSLAM(M)
+    x_gt = [0, 0, 0]
+    for t, s in enumerate(steps(g)[:12]):
+        ut = [float(s["ut"][0]), float(s["ut"][1])]
+        x_gt = F.true_pose_step(x_gt, ut)
+        tr, tp, tv = _truth(x_gt, lm)
+        idx = ctx.fs_step(ut[0], ut[1], F.DT, F.ALPHA, tr, tp, tv, s["ints"], s["normals"],
+                          float(s["r_uniform"][0]) * 1 / M, want_idx=True)
+        orc.step(ut, s["ints"], s["normals"], float(s["r_uniform"][0]))
+        assert np.array_equal(idx, orc.last_idx), t
+
+
+def test_capacity_overflow_is_reported():
+    from slam_amd import _lib as L
+    g = load("fastslam_seed0")
+    M = int(g["M"])
+    lm = g["landmarks"].astype(np.float32)
+    ctx = L.Context(0, L.F64)
+    ctx.fs_init(M, 1)
+    s = steps(g)[0]
+    ut = [float(s["ut"][0]), float(s["ut"][1])]
+    tr, tp, tv = _truth(F.true_pose_step([0, 0, 0], ut), lm)
+    with pytest.raises(L.MclHipError, match="feature slots"):
+        ctx.fs_step(ut[0], ut[1], F.DT, F.ALPHA, tr, tp, tv, s["ints"], s["normals"], 0.001)
+
+
+def test_large_population_with_device_noise():
+    """2^18 particles, 64 landmarks on a ring, device generators: properties only."""
+    from slam_amd import _lib as L
+    M, nl = 1 << 18, 64
+    ang = np.arange(nl) * 2 * np.pi / nl
+    lm = np.stack([12 * np.cos(ang) + 3, 12 * np.sin(ang) - 6, np.zeros(nl)], 1).astype(np.float32)
+    ctx = L.Context(0, L.F64)
+    ctx.fs_init(M, 96)
+    x_gt = [0, 0, 0]
+    for t in range(6):
+        ut = [25, 0.001] if t < 4 else [25, -np.pi / 2 * 5]
+        x_gt = F.true_pose_step(x_gt, ut)
+        tr, tp, tv = _truth(x_gt, lm)
+        idx = ctx.fs_step(ut[0], ut[1], F.DT, F.ALPHA, tr, tp, tv, None, None, 0.37 / M, seed=100 + t, want_idx=True)
+        assert np.all(np.diff(idx) >= 0) and idx[0] >= 0 and idx[-1] < M
+    st = ctx.fs_get_state()
+    assert np.all(np.isfinite(st["pose"])) and np.all(st["nfeat"] > 0) and np.all(st["nfeat"] <= 96)
+    assert np.all(np.isfinite(st["w"])) and np.all(st["w"] > 0) and np.all(st["w"] <= 1)
+    # pose cloud centred near the true pose
+    assert np.linalg.norm(st["pose"][:, :2].mean(0) - np.array(x_gt[:2], float)) < 1.0
+    det = st["f_cov"][:, :, 0, 0] * st["f_cov"][:, :, 1, 1] - st["f_cov"][:, :, 0, 1] * st["f_cov"][:, :, 1, 0]
+    live = np.arange(96)[None, :] < st["nfeat"][:, None]
+    assert np.all(det[live] > 0)

@@ -545,13 +545,92 @@ def case_grid():
         print("wrote", name, "steps", len(controls), "pk max", float(robot.pk.max()), "dtype", robot.pk.dtype)
 
 
+def case_fastslam():
+    """FastSLAM 1.0 (13_fast_slam/fast_slam1.py): the reference's FastSLAM object driven by its own
+    __main__ controls under a seeded np.random, plotting switched off; the random numbers every
+    step consumed and the full particle state after it are captured."""
+    import importlib.util
+    fs_dir = "/root/reference/13_fast_slam"
+    spec = importlib.util.spec_from_file_location("ref_fast_slam1", os.path.join(fs_dir, "fast_slam1.py"))
+    fs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fs)
+    fs.FastSLAM.plot = lambda self: None
+    tm = fs.tm
+
+    def control_at(t):     # the schedule of fast_slam1.py:539-559
+        turn = [25, -np.pi / 2 * 5]
+        straight = [25, 0.001]
+        if t <= 7 * tm: return straight
+        if t <= 9 * tm: return turn
+        if t <= 10 * tm: return straight
+        if t <= 12 * tm: return turn
+        if t <= 17 * tm: return straight
+        if t <= 19 * tm: return turn
+        if t <= 20 * tm: return straight
+        if t <= 22 * tm: return turn
+        return straight
+
+    for name, seed, n_steps in (("fastslam_seed0", 0, 26), ("fastslam_seed3", 3, 12)):
+        np.random.seed(seed)
+        slam = fs.FastSLAM()
+        M = slam.M
+        out = {"seed": np.array(seed), "n_steps": np.array(n_steps), "M": np.array(M),
+               "landmarks": np.array(fs.landmarks, np.float64), "dt": np.array(fs.dt)}
+        cap = 0
+        recs = []
+        for t in range(n_steps):
+            ints, normals, uniforms = [], [], []
+            o_randint, o_randn, o_rand = np.random.randint, np.random.randn, np.random.rand
+
+            def spy_randint(*a, **k):
+                v = o_randint(*a, **k); ints.append(np.array(v)); return v
+
+            def spy_randn(*a, **k):
+                v = o_randn(*a, **k); normals.append(float(v)); return v
+
+            def spy_rand(*a, **k):
+                v = o_rand(*a, **k); uniforms.append(float(v)); return v
+
+            np.random.randint, np.random.randn, np.random.rand = spy_randint, spy_randn, spy_rand
+            try:
+                with contextlib.redirect_stdout(io.StringIO()):
+                    ut = control_at(t)
+                    slam.control(ut)
+            finally:
+                np.random.randint, np.random.randn, np.random.rand = o_randint, o_randn, o_rand
+            rec = {"ut": np.array(ut, np.float64), "ints": np.array(ints).reshape(M, 3, 12).astype(np.int16),
+                   "normals": np.array(normals).reshape(M, -1), "r_uniform": np.array(uniforms),
+                   "x_gt": np.array(slam.x_gt[-1], np.float64),
+                   "pose": np.stack([y.x[-1][:, 0] for y in slam.Y]),
+                   "w": np.array([y.w for y in slam.Y]), "nfeat": np.array([len(y.feature) for y in slam.Y]),
+                   "new_id": np.array([y.new_feature_id for y in slam.Y])}
+            cap = max(cap, int(rec["nfeat"].max()))
+            rec["_feat"] = [[(f.m[:, 0].copy(), f.Cov.copy(), f.i, f.w, f.id, bool(f.updated)) for f in y.feature] for y in slam.Y]
+            recs.append(rec)
+        for t, rec in enumerate(recs):
+            feats = rec.pop("_feat")
+            fm = np.zeros((M, cap, 2)); fc = np.zeros((M, cap, 2, 2)); fi = np.zeros((M, cap), np.int64)
+            fw = np.zeros((M, cap)); fid = np.full((M, cap), -1, np.int64); fu = np.zeros((M, cap), bool)
+            for k, fl in enumerate(feats):
+                for j, (m, C, i, w, idn, upd) in enumerate(fl):
+                    fm[k, j], fc[k, j], fi[k, j], fw[k, j], fid[k, j], fu[k, j] = m, C, i, w, idn, upd
+            rec.update({"f_m": fm, "f_cov": fc, "f_i": fi, "f_w": fw, "f_id": fid, "f_updated": fu})
+            for k, v in rec.items():
+                out["s%d_%s" % (t, k)] = v
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+        print("wrote", name, "steps", n_steps, "max features", cap, "normals per particle",
+              [r["normals"].shape[1] for r in recs][:8])
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["demo", "robot", "px", "resample", "motion", "synth", "amcl", "grid"]
+    which = sys.argv[1:] or ["demo", "robot", "px", "resample", "motion", "synth", "amcl", "grid", "fastslam"]
     if "amcl" in which:
         case_amcl()
     if "grid" in which:
         case_grid()
+    if "fastslam" in which:
+        case_fastslam()
     if "demo" in which:
         case_reference_demo()
     if "robot" in which:
