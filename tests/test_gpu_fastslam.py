@@ -110,3 +110,21 @@ def test_large_population_with_device_noise():
     det = st["f_cov"][:, :, 0, 0] * st["f_cov"][:, :, 1, 1] - st["f_cov"][:, :, 0, 1] * st["f_cov"][:, :, 1, 0]
     live = np.arange(96)[None, :] < st["nfeat"][:, None]
     assert np.all(det[live] > 0)
+
+
+def test_dropin_class_follows_reference_run():
+    """slam_amd.fast_slam1.FastSLAM driven like fast_slam1.py:536-561 under the same np.random seed:
+    the host draws the random numbers in the reference's order, so every step sees the same stream."""
+    from slam_amd import fast_slam1 as S
+    g = load("fastslam_seed3")
+    np.random.seed(int(g["seed"]))
+    slam = S.FastSLAM()
+    for t, s in enumerate(steps(g)):
+        ut = [float(s["ut"][0]), float(s["ut"][1])]
+        slam.control(ut)
+        assert np.array_equal(np.array(slam.x_gt[-1], np.float64), s["x_gt"])
+        _compare(slam.state(), s, t)
+    Y = slam.Y
+    assert len(Y) == slam.M and len(Y[0].x) == len(steps(g)) + 1
+    assert [len(y.feature) for y in Y] == list(s["nfeat"])
+    assert Y[5].feature[0].m.shape == (2, 1) and Y[5].feature[0].Cov.shape == (2, 2)
