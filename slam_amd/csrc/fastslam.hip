@@ -143,68 +143,93 @@ __global__ __launch_bounds__(128) void fs_step_kernel(FsParams P) {
   }
 
   // ---- every landmark: draw the measurement, associate, create or update (:286-375) ----
+  // The association of a measurement reads only what the prediction pass stored (z_pred, invQ,
+  // det Q of the features that existed before this step), never what an earlier measurement of
+  // the same step changed.  So eight measurements are associated together -- one sweep over the
+  // stored features serves all eight -- and then applied one by one in landmark order.
+  constexpr int kChunk = 8;
   int used = 0;
-  for (int l = 0; l < P.L; ++l) {
-    if (!P.tvalid[l]) continue;                 // measure() returns r_max + 1: skipped at :291
-    double n_r, n_phi;
-    if (P.normals) {
-      n_r = P.normals[p * P.n_norm + used];
-      n_phi = P.normals[p * P.n_norm + used + 1];
-    } else {
-      n_r = device_normal((uint64_t)p, (uint32_t)used, P.seed);
-      n_phi = device_normal((uint64_t)p, (uint32_t)used + 1u, P.seed);
+  int l = 0;
+  while (l < P.L) {
+    double mzr[kChunk], mzphi[kChunk], best_w[kChunk];
+    int best_c[kChunk];
+    int nm = 0;
+    for (; l < P.L && nm < kChunk; ++l) {
+      if (!P.tvalid[l]) continue;               // measure() returns r_max + 1: skipped at :291
+      double n_r, n_phi;
+      if (P.normals) {
+        n_r = P.normals[p * P.n_norm + used];
+        n_phi = P.normals[p * P.n_norm + used + 1];
+      } else {
+        n_r = device_normal((uint64_t)p, (uint32_t)used, P.seed);
+        n_phi = device_normal((uint64_t)p, (uint32_t)used + 1u, P.seed);
+      }
+      used += 2;
+      const double zr = P.tr[l] + n_r * P.std_r;   // :145-152
+      double zphi = P.tphi[l] + n_phi * P.std_phi;
+      if (zphi > M_PI) zphi -= 2 * M_PI;
+      else if (zphi < -M_PI) zphi += 2 * M_PI;
+      if (!(zr <= P.r_max)) continue;           // :291
+      mzr[nm] = zr; mzphi[nm] = zphi; best_w[nm] = 0.0; best_c[nm] = -1;
+      ++nm;
     }
-    used += 2;
-    const double zr = P.tr[l] + n_r * P.std_r;  // :145-152
-    double zphi = P.tphi[l] + n_phi * P.std_phi;
-    if (zphi > M_PI) zphi -= 2 * M_PI;
-    else if (zphi < -M_PI) zphi += 2 * M_PI;
-    if (!(zr <= P.r_max)) continue;             // :291
-    int c = -1;
-    double w_max = 0.0;
+    if (nm == 0) continue;
     for (int j = 0; j < n_old; ++j) {
-      const double e0 = zr - AT(P.zr, j);
-      const double e1 = wrap_residual(zphi - AT(P.zphi, j));
-      const double t0 = e0 * AT(P.iq00, j) + e1 * AT(P.iq10, j);   // r.T @ invQ
-      const double t1 = e0 * AT(P.iq01, j) + e1 * AT(P.iq11, j);
-      const double d2 = t0 * e0 + t1 * e1;
-      if (d2 <= P.gate2) {                      // :307
-        const double eta = 1.0 / (2.0 * M_PI * sqrt(AT(P.detq, j)));
-        const double wj = eta * exp(-0.5 * d2);
-        if (w_max < wj) { w_max = wj; c = j; }
+      const double fr = AT(P.zr, j), fphi = AT(P.zphi, j);
+      const double q00 = AT(P.iq00, j), q01 = AT(P.iq01, j), q10 = AT(P.iq10, j), q11 = AT(P.iq11, j);
+      const double dq = AT(P.detq, j);
+#pragma unroll
+      for (int u = 0; u < kChunk; ++u) {
+        if (u < nm) {
+          const double e0 = mzr[u] - fr;
+          const double e1 = wrap_residual(mzphi[u] - fphi);
+          const double t0 = e0 * q00 + e1 * q10;   // r.T @ invQ
+          const double t1 = e0 * q01 + e1 * q11;
+          const double d2 = t0 * e0 + t1 * e1;
+          if (d2 <= P.gate2) {                  // :307
+            const double eta = 1.0 / (2.0 * M_PI * sqrt(dq));
+            const double wj = eta * exp(-0.5 * d2);
+            if (best_w[u] < wj) { best_w[u] = wj; best_c[u] = j; }
+          }
+        }
       }
     }
-    if (c == -1) {                              // new feature (:318-347)
-      if (n >= P.F) { atomicMax(P.overflow, 1); continue; }
-      const double m0 = zr * cos(zphi + th) + x, m1 = zr * sin(zphi + th) + y;   // :201-202
-      double r_, phi_;
-      M2 H;
-      predict_measurement(m0, m1, x, y, th, &r_, &phi_, &H);
-      const M2 iH = inv_lu(H, nullptr);
-      const M2 Qt{P.qt_r, 0.0, 0.0, P.qt_phi};
-      const M2 C = mul(mul(iH, Qt), tr(iH));   // :336
-      AT(P.fm0, n) = m0; AT(P.fm1, n) = m1;
-      AT(P.c00, n) = C.a; AT(P.c01, n) = C.b; AT(P.c10, n) = C.c; AT(P.c11, n) = C.d;
-      AT(P.fi, n) = 1; AT(P.fw, n) = P.p0; AT(P.fid, n) = P.new_id[p];
-      AT(P.upd, n) = 1;
-      P.new_id[p] += 1;
-      ++n;
-    } else {                                    // EKF update (:348-375)
-      const M2 H{AT(P.h00, c), AT(P.h01, c), AT(P.h10, c), AT(P.h11, c)};
-      const M2 iq{AT(P.iq00, c), AT(P.iq01, c), AT(P.iq10, c), AT(P.iq11, c)};
-      const M2 C{AT(P.c00, c), AT(P.c01, c), AT(P.c10, c), AT(P.c11, c)};
-      const M2 K = mul(mul(C, tr(H)), iq);     // :360
-      const double e0 = zr - AT(P.zr, c);
-      const double e1 = wrap_residual(zphi - AT(P.zphi, c));
-      AT(P.fm0, c) = AT(P.fm0, c) + (K.a * e0 + K.b * e1);   // :369
-      AT(P.fm1, c) = AT(P.fm1, c) + (K.c * e0 + K.d * e1);
-      const M2 KH = mul(K, H);
-      const M2 IKH{1.0 - KH.a, 0.0 - KH.b, 0.0 - KH.c, 1.0 - KH.d};
-      const M2 Cn = mul(IKH, C);               // :370
-      AT(P.c00, c) = Cn.a; AT(P.c01, c) = Cn.b; AT(P.c10, c) = Cn.c; AT(P.c11, c) = Cn.d;
-      AT(P.fi, c) = AT(P.fi, c) + 1;
-      AT(P.upd, c) = 1;
-      AT(P.fw, c) = w_max;
+#pragma unroll 1
+    for (int u = 0; u < nm; ++u) {
+      const double zr = mzr[u], zphi = mzphi[u], w_max = best_w[u];
+      const int c = best_c[u];
+      if (c == -1) {                              // new feature (:318-347)
+        if (n >= P.F) { atomicMax(P.overflow, 1); continue; }
+        const double m0 = zr * cos(zphi + th) + x, m1 = zr * sin(zphi + th) + y;   // :201-202
+        double r_, phi_;
+        M2 H;
+        predict_measurement(m0, m1, x, y, th, &r_, &phi_, &H);
+        const M2 iH = inv_lu(H, nullptr);
+        const M2 Qt{P.qt_r, 0.0, 0.0, P.qt_phi};
+        const M2 C = mul(mul(iH, Qt), tr(iH));   // :336
+        AT(P.fm0, n) = m0; AT(P.fm1, n) = m1;
+        AT(P.c00, n) = C.a; AT(P.c01, n) = C.b; AT(P.c10, n) = C.c; AT(P.c11, n) = C.d;
+        AT(P.fi, n) = 1; AT(P.fw, n) = P.p0; AT(P.fid, n) = P.new_id[p];
+        AT(P.upd, n) = 1;
+        P.new_id[p] += 1;
+        ++n;
+      } else {                                    // EKF update (:348-375)
+        const M2 H{AT(P.h00, c), AT(P.h01, c), AT(P.h10, c), AT(P.h11, c)};
+        const M2 iq{AT(P.iq00, c), AT(P.iq01, c), AT(P.iq10, c), AT(P.iq11, c)};
+        const M2 C{AT(P.c00, c), AT(P.c01, c), AT(P.c10, c), AT(P.c11, c)};
+        const M2 K = mul(mul(C, tr(H)), iq);     // :360
+        const double e0 = zr - AT(P.zr, c);
+        const double e1 = wrap_residual(zphi - AT(P.zphi, c));
+        AT(P.fm0, c) = AT(P.fm0, c) + (K.a * e0 + K.b * e1);   // :369
+        AT(P.fm1, c) = AT(P.fm1, c) + (K.c * e0 + K.d * e1);
+        const M2 KH = mul(K, H);
+        const M2 IKH{1.0 - KH.a, 0.0 - KH.b, 0.0 - KH.c, 1.0 - KH.d};
+        const M2 Cn = mul(IKH, C);               // :370
+        AT(P.c00, c) = Cn.a; AT(P.c01, c) = Cn.b; AT(P.c10, c) = Cn.c; AT(P.c11, c) = Cn.d;
+        AT(P.fi, c) = AT(P.fi, c) + 1;
+        AT(P.upd, c) = 1;
+        AT(P.fw, c) = w_max;
+      }
     }
   }
 
