@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--regime", default="global", choices=["global", "tracking"],
                     help="global: every step starts from the uniform synthetic cloud; tracking: the filter runs on")
     ap.add_argument("--cpu-particles", type=int, default=1024, help="particles of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--rehearse-collectives", action="store_true",
+                    help="run the multi-rank code path (RCCL group, cross-rank resampling) even with one rank")
     return ap.parse_args()
 
 
@@ -88,15 +90,24 @@ def profiled_traffic(args):
 
 def main():
     a = parse()
+    # stdout carries exactly one JSON line: whatever libraries print on the way (RCCL's version banner
+    # goes to stdout) is sent to stderr instead
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or a.rehearse_collectives:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from slam_amd import _lib, workload as W
     from slam_amd.sharded import ShardedFilter
 
@@ -125,7 +136,7 @@ def main():
     rs = np.random.RandomState(W.SEED_STREAM)
     r_draw = rs.rand(n_total) / (M * world)
     alpha = [4, 2, 4, 4, 4, 2]
-    filt = ShardedFilter(ctx, dist, rank, world, M)
+    filt = ShardedFilter(ctx, dist, rank, world, M, force_collectives=a.rehearse_collectives)
 
     def one_step(t):
         if a.regime == "global":
@@ -192,7 +203,8 @@ def main():
         }
         if world == 1 and a.cpu_particles > 0:
             out["cpu_baseline"] = cpu_baseline(grid, angles, X, z_meas[0], ctrl[0], a.cpu_particles)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

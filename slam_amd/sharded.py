@@ -141,12 +141,13 @@ def sequential_sum(values):
 class ShardedFilter:
     """Drives one MCL update per call over `world` ranks."""
 
-    def __init__(self, ctx_or_backend, dist, rank, world, m_local, weight_mode=_lib.W_LOG):
+    def __init__(self, ctx_or_backend, dist, rank, world, m_local, weight_mode=_lib.W_LOG, force_collectives=False):
         self.b = HipShardBackend(ctx_or_backend) if isinstance(ctx_or_backend, _lib.Context) else ctx_or_backend
         self.dist, self.rank, self.world, self.mode = dist, rank, world, weight_mode
         self.m_local = int(m_local)
         self.last_idx = None
-        if world > 1:
+        self.collective = world > 1 or force_collectives   # a single rank may run the cross-rank path too (tests)
+        if self.collective:
             self.coll = _Coll(dist, rank, world)
             sizes = self.coll.allgather_bytes(np.int64(self.m_local).tobytes())
             self.sizes = [int(np.frombuffer(s, np.int64)[0]) for s in sizes]
@@ -161,7 +162,7 @@ class ShardedFilter:
 
     def step(self, v, omega, dt, alpha, z_meas, r, seed=0, noise_ints=None, want_idx=False):
         """r = (uniform draw) / M_total, identical on every rank."""
-        if self.world == 1:
+        if not self.collective:
             self.b.step_single(v, omega, dt, alpha, z_meas, r, noise_ints, seed, self.mode, wait=want_idx)
             return
         b, co, rank, world = self.b, self.coll, self.rank, self.world

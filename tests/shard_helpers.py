@@ -94,13 +94,13 @@ class NumpyShardBackend:
         return row0_global + j
 
 
-def run_ranks(fn, world, *args):
-    """fn(rank, world, port, queue, *args) in `world` processes; returns the per-rank results."""
+def run_ranks(fn, world, *args, backend="gloo"):
+    """fn(rank, world, dist, *args) in `world` fresh processes; returns the per-rank results."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=_entry, args=(fn, r, world, port, q) + args) for r in range(world)]
+    procs = [ctx.Process(target=_entry, args=(backend, fn, r, world, port, q) + args) for r in range(world)]
     for p in procs:
         p.start()
     out = {}
@@ -115,12 +115,17 @@ def run_ranks(fn, world, *args):
     return [out[r] for r in range(world)]
 
 
-def _entry(fn, rank, world, port, q, *args):
+def _entry(backend, fn, rank, world, port, q, *args):
     try:
+        import torch
         import torch.distributed as dist
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        if backend == "nccl":    # torch brings up its HIP runtime before the library is loaded, as bench.py does
+            torch.cuda.set_device(rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         val = fn(rank, world, dist, *args)
         dist.barrier()
         dist.destroy_process_group()

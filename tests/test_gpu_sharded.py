@@ -63,3 +63,37 @@ def test_two_ranks_equal_one_context(sizes, dtype, mode, devnoise):
     assert np.array_equal(np.concatenate([x["idx"] for x in res]), idx)
     assert np.array_equal(np.concatenate([x["X"] for x in res]), Xr)
     assert np.array_equal(np.concatenate([x["w"] for x in res]), wr)
+
+
+def _rccl_rank_fn(rank, world, dist, M, z_meas):
+    from slam_amd import _lib
+    from slam_amd.sharded import ShardedFilter
+    X, noise, r = _inputs(M)
+    ctx = _setup(_lib.F64)
+    ctx.set_particles(X)
+    f = ShardedFilter(ctx, dist, 0, 1, M, weight_mode=_lib.W_LOG, force_collectives=True)
+    assert f.coll.backend == "nccl" and f.coll.dev.type == "cuda"
+    f.step(1.5, 0.0, 0.1, ALPHA, z_meas, r, seed=99, noise_ints=noise, want_idx=True)
+    Xo, wo, _ = ctx.get_particles()
+    return {"idx": f.last_idx, "X": Xo, "w": wo, "total": f.total}
+
+
+def test_rccl_path_with_device_tensors_on_one_rank():
+    """The cross-rank path under the "nccl" backend (RCCL) with a group of one, in a fresh process
+    that brings torch's HIP runtime up first (as bench.py does): the collectives run on GPU
+    tensors, and packed rows travel between torch's device memory and the library's through raw
+    device pointers -- the pieces the gloo tests cannot reach.  Result: bit-equal to the fused step."""
+    from slam_amd import _lib
+    M = 24576
+    X, noise, r = _inputs(M)
+    ref = _setup(_lib.F64)
+    z_meas = ref.raycast(np.array([3.0, 4.5, 0.0]), want_hits=False)[0][0]
+    ref.set_particles(X)
+    ref.sample(1.5, 0.0, 0.1, ALPHA, z_meas, noise, seed=99)
+    total = ref.normalise(_lib.W_LOG)
+    idx = ref.resample(r, _lib.RESAMPLE_PARALLEL)
+    Xr, wr, _ = ref.get_particles()
+    res = run_ranks(_rccl_rank_fn, 1, M, z_meas, backend="nccl")[0]
+    assert res["total"] == total
+    assert np.array_equal(res["idx"], idx)
+    assert np.array_equal(res["X"], Xr) and np.array_equal(res["w"], wr)
