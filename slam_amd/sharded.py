@@ -86,15 +86,31 @@ class _Coll:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return t.cpu().numpy()
 
-    def allgather_bytes(self, payload, max_len=None):
-        """Every rank's byte string, in rank order (lengths may differ)."""
+    def allgather_bytes(self, payload, cap=None):
+        """Every rank's byte string, in rank order (lengths may differ).  With `cap` (the same on
+        every rank) one collective does it as long as every payload fits in cap bytes: the length
+        travels in front of the payload; otherwise lengths are exchanged first."""
         torch = self.torch
+        if cap is not None:
+            buf = np.zeros(8 + cap, np.uint8)
+            buf[:8] = np.frombuffer(np.int64(len(payload)).tobytes(), np.uint8)
+            fits = len(payload) <= cap
+            if fits:
+                buf[8:8 + len(payload)] = np.frombuffer(payload, np.uint8)
+            t = self._t(buf, torch.uint8)
+            outs = [torch.zeros_like(t) for _ in range(self.world)]
+            self.dist.all_gather(outs, t)
+            outs = [o.cpu().numpy() for o in outs]
+            lens = [int(np.frombuffer(o[:8].tobytes(), np.int64)[0]) for o in outs]
+            if all(n <= cap for n in lens):
+                return [o[8:8 + lens[i]].tobytes() for i, o in enumerate(outs)]
+            # some rank did not fit (every rank sees that): fall through to the two-step exchange
         n = self._t([len(payload)], torch.int64)
         lens = [torch.zeros_like(n) for _ in range(self.world)]
         self.dist.all_gather(lens, n)
         lens = [int(x.cpu()[0]) for x in lens]
-        cap = max(max(lens), 1)
-        buf = np.zeros(cap, np.uint8)
+        size = max(max(lens), 1)
+        buf = np.zeros(size, np.uint8)
         buf[:len(payload)] = np.frombuffer(payload, np.uint8)
         t = self._t(buf, torch.uint8)
         outs = [torch.zeros_like(t) for _ in range(self.world)]
@@ -157,6 +173,7 @@ class ShardedFilter:
             self.firsts = [int(x) for x in np.concatenate([[0], np.cumsum(self.sizes)])]
             self.m_total = self.firsts[-1]
             self.b.set_range(self.firsts[rank], self.m_total)
+            self.chunk_cap = 8 * max((n + CHUNK - 1) // CHUNK for n in self.sizes)   # bytes of the longest chunk-sum list
         else:
             self.sizes, self.firsts, self.m_total = [self.m_local], [0, self.m_local], self.m_local
 
@@ -170,7 +187,7 @@ class ShardedFilter:
         gmax = co.allreduce_max(b.max_logw()) if self.mode == _lib.W_LOG else 0.0
         # global sum in numpy's order: chunk sums of all ranks, added left to right
         chunks = b.weights(self.mode, gmax)
-        all_chunks = [np.frombuffer(x, np.float64) for x in co.allgather_bytes(chunks.tobytes())]
+        all_chunks = [np.frombuffer(x, np.float64) for x in co.allgather_bytes(chunks.tobytes(), cap=self.chunk_cap)]
         total = sequential_sum(np.concatenate(all_chunks))
         self.total = total
         below = float(np.sum(np.concatenate(all_chunks[:rank]))) if rank else 0.0
@@ -180,7 +197,7 @@ class ShardedFilter:
         k_total, nrec = b.scan(total, approx_offset)
         recs = b.get_records(nrec)
         head = np.array([k_total, nrec], np.uint64).tobytes()
-        parts = co.allgather_bytes(head + recs.tobytes())
+        parts = co.allgather_bytes(head + recs.tobytes(), cap=16 + 24 * 256)   # a few records per rank is the rule
         k_tot = [int(np.frombuffer(p[:16], np.uint64)[0]) for p in parts]
         n_rec = [int(np.frombuffer(p[:16], np.uint64)[1]) for p in parts]
         p_off = [0] * world
