@@ -73,6 +73,39 @@ __device__ inline double wave_sum(double v) {
                               (unsigned int)__builtin_amdgcn_readlane((int)__double_as_longlong(v), 63));
 }
 
+// Bearing of (dx, dy) in [0, 2pi), float32, |error| < 1e-6 rad for finite inputs (0 for dx = dy = 0,
+// as atan2 gives).  Only used to pick candidate beams: decisions within 1e-5 rad of a sector edge
+// are taken again with the float64 atan2.  Odd minimax polynomial of degree 15 for atan on [0, 1]
+// (1.4e-7), v_rcp_f32 for the ratio, three reflections.
+__device__ inline float bearing_f32(float dy, float dx) {
+  const float ax = fabsf(dx), ay = fabsf(dy);
+  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  const float t = mn * __builtin_amdgcn_rcpf(mx);
+  const float s = t * t;
+  float p = -0.004054124001413584f;
+  p = fmaf(p, s, 0.021861203014850616f);
+  p = fmaf(p, s, -0.05590951070189476f);
+  p = fmaf(p, s, 0.09641963243484497f);
+  p = fmaf(p, s, -0.13908521831035614f);
+  p = fmaf(p, s, 0.19946539402008057f);
+  p = fmaf(p, s, -0.33329856395721436f);
+  p = fmaf(p, s, 0.9999993443489075f);
+  float r = t * p;
+  r = ay > ax ? 1.5707964f - r : r;
+  r = dx < 0.0f ? 3.1415927f - r : r;
+  r = dy < 0.0f ? 6.2831855f - r : r;
+  return mx > 0.0f ? r : 0.0f;
+}
+
+// float64 bearing in [0, 2pi) exactly as the reference forms it (mc_localization.py:133-135).
+// Kept out of line: it runs for a few cells in a thousand, and inlined its two dozen polynomial
+// constants would sit in registers of the hot loop.
+__device__ __attribute__((noinline)) double exact_bearing(double dy, double dx) {
+  double a = atan2(dy, dx);
+  if (a < 0.0) a += kTwoPi;
+  return a;
+}
+
 // Profiling build (-DMCL_STAMPS): cycles spent per section, summed over waves, in P.stamps.
 #ifdef MCL_STAMPS
 #define STAMP(i) do { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); acc[i] += t__ - t_last; t_last = t__; } while (0)
@@ -197,9 +230,7 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
       COUNT(1);
       if (valid && r2 <= P.r2max) {       // :127
         COUNTL(2);
-        float af = atan2f((float)dy, (float)dx);
-        if (af < 0.0f) af += 6.2831855f;
-        const double aa = (double)af;
+        const double aa = (double)bearing_f32((float)dy, (float)dx);
         const unsigned long long r2bits = (unsigned long long)__double_as_longlong(r2);
         const unsigned long long cellbits = (unsigned long long)((unsigned int)row * (unsigned int)P.W + (unsigned int)col);
         // beams whose table angle lies within `reach` of aa - th + c*2pi, c in {-1, 0, 1}
@@ -256,12 +287,7 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
             if (any_edge) {                                 // rare: exact float64 bearing
               COUNT(6);
               if (!have_exact) {
-                // the empty asm pins the evaluation inside this branch (it must not be hoisted and
-                // run for every cell)
-                double dyo = dy, dxo = dx;
-                asm volatile("" : "+v"(dyo), "+v"(dxo));
-                a_exact = atan2(dyo, dxo);                  // :133
-                if (a_exact < 0.0) a_exact += kTwoPi;       // :134-135
+                a_exact = exact_bearing(dy, dx);            // :133-135
                 have_exact = true;
               }
 #pragma unroll 1
