@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--regime", default="global", choices=["global", "tracking"],
                     help="global: every step starts from the uniform synthetic cloud; tracking: the filter runs on")
-    ap.add_argument("--cpu-particles", type=int, default=1024, help="particles of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-particles", type=int, default=8192, help="particles of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--rehearse-collectives", action="store_true",
                     help="run the multi-rank code path (RCCL group, cross-rank resampling) even with one rank")
     return ap.parse_args()

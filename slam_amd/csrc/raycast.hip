@@ -17,7 +17,7 @@
 // exact float64 dx, dy, r2; a float32 bearing picks the window of the sorted
 // beam table the cell can fall into (the table is extended by images of the
 // top beams shifted by -2pi, so one window also covers the seam); the window's
-// eight entries are read from LDS together; a cell that is not closer than an
+// entries are read from LDS four at a time; a cell that is not closer than an
 // entry's current minimum is dropped before any angle test; only where the
 // float32 bearing is within 1e-5 rad of a sector edge is the float64 atan2
 // evaluated and the reference predicate applied literally.  Each (cell, beam)
@@ -36,7 +36,10 @@ namespace mcl {
 
 constexpr double kTwoPi = 6.283185307179586;  // == np.pi*2.0
 constexpr int kWavesPerBlock = 4;
-constexpr int kGroup = 8;           // beams examined per step of the matching loop
+#ifndef MCL_GROUP
+#define MCL_GROUP 4
+#endif
+constexpr int kGroup = MCL_GROUP;   // beams examined per step of the matching loop
 constexpr int kWaveScratch = 128;     // u32 words of per-wave LDS scratch: the ring of cells waiting to be matched
 
 // ---- cross-lane helpers on the DPP path (no LDS round trip) ----------------
@@ -106,6 +109,10 @@ __device__ __attribute__((noinline)) double exact_bearing(double dy, double dx) 
   return a;
 }
 
+// float64 logarithm for the arguments the fast path does not take (zero, subnormal, infinite, NaN);
+// out of line for the same reason
+__device__ __attribute__((noinline)) double slow_log(double v) { return log(v); }
+
 // Profiling build (-DMCL_STAMPS): cycles spent per section, summed over waves, in P.stamps.
 #ifdef MCL_STAMPS
 #define STAMP(i) do { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); acc[i] += t__ - t_last; t_last = t__; } while (0)
@@ -122,8 +129,10 @@ __device__ __attribute__((noinline)) double exact_bearing(double dy, double dx) 
 #define COUNTL(i) do { } while (0)
 #endif
 
+// Occupancy target: five waves per SIMD (<= 96 VGPRs).  Measured at 2^20 x 180: 3 waves 2.32 ms,
+// 4 waves 1.88 ms, 5 waves 1.62 ms, 6 waves (spills) 1.65 ms.
 #ifndef MCL_RAY_WAVES
-#define MCL_RAY_WAVES 3
+#define MCL_RAY_WAVES 5
 #endif
 template <typename T, bool STAGE, bool PRODUCT, bool GRID = false>
 __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
@@ -258,7 +267,7 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
             i0 = s_lut[bkt];
           }
           if (!(seam && c + 1 <= c_hi) && i0 < G) i0 = G;   // images stand for window c + 1: skip them if it is not allowed
-          // beams are visited eight at a time: all sixteen LDS reads of a group are issued
+          // beams are visited kGroup at a time: all LDS reads of a group are issued
           // before the first use, so their latency is paid once per group, not once per beam
 #pragma unroll 1
           for (int kb = i0; kb < NX; kb += kGroup) {
@@ -420,7 +429,7 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
         if constexpr (sizeof(R) == 4) {
           const long long bits = __double_as_longlong(v);
           const int ex = (int)((bits >> 52) & 0x7ff);
-          if (ex == 0 || ex == 0x7ff || bits < 0) return log(v);   // zero, subnormal, infinite, NaN, negative
+          if (ex == 0 || ex == 0x7ff || bits < 0) return slow_log(v);   // zero, subnormal, infinite, NaN, negative
           const double mant = __longlong_as_double((bits & 0x000fffffffffffffll) | 0x3ff0000000000000ll);
           return ((double)(ex - 1023) + (double)__builtin_amdgcn_logf((float)mant)) * 0.6931471805599453;
         } else {
