@@ -129,10 +129,10 @@ __device__ __attribute__((noinline)) double slow_log(double v) { return log(v); 
 #define COUNTL(i) do { } while (0)
 #endif
 
-// Occupancy target: five waves per SIMD (<= 96 VGPRs).  Measured at 2^20 x 180: 3 waves 2.32 ms,
-// 4 waves 1.88 ms, 5 waves 1.62 ms, 6 waves (spills) 1.65 ms.
+// Occupancy target: six waves per SIMD (80 VGPRs, nine of them spilled).  Measured at 2^20 x 180:
+// 3 waves 2.32 ms, 4 waves 1.88 ms, 5 waves 1.61 ms, 6 waves 1.58 ms, 8 waves (34 spills) 2.27 ms.
 #ifndef MCL_RAY_WAVES
-#define MCL_RAY_WAVES 5
+#define MCL_RAY_WAVES 6
 #endif
 template <typename T, bool STAGE, bool PRODUCT, bool GRID = false>
 __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: particle index, pose and slice bounds live in scalar registers
   unsigned long long* const rmin = s_rmin_all + (size_t)wv * NXP;  // per extended-table entry: bits of the smallest r2
   unsigned long long* const aux = s_aux_all + (size_t)wv * NXP;    // STAGE: hit cell per entry; PRODUCT: p_k in caller order
   unsigned int* const ring = s_walk_all + (size_t)wv * kWaveScratch;   // [128] cells waiting to be matched
@@ -202,10 +202,6 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
     STAMP(7);
     const double x = (double)nx, y = (double)ny, th = (double)nth;
     const bool on_free = npm != 0;
-    if (p + stride < n) {   // next pose in flight
-      nx = xs[p + stride]; ny = ys[p + stride]; nth = ths[p + stride];
-      if (!STAGE && !GRID) npm = pm[p + stride];
-    }
     for (int k = lane; k < NXP; k += 64) {
       rmin[k] = r2max_bits;
       if (STAGE) aux[k] = 0xffffffffull;
@@ -381,6 +377,10 @@ __global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
 
     // ranges -> beam mixture -> weight
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (p + stride < n) {   // next pose in flight while this particle's weight is computed
+      nx = xs[p + stride]; ny = ys[p + stride]; nth = ths[p + stride];
+      if (!STAGE && !GRID) npm = pm[p + stride];
+    }
     if (STAGE) {
       for (int k = lane; k < B; k += 64) {
         const double r2 = __longlong_as_double((long long)rmin[G + k]);

@@ -1,7 +1,9 @@
 #!/bin/bash
-# Benchmarks every slam_amd/libmclhip_v_*.so variant build (kernel time of the sector query).
+# Benchmarks every slam_amd/libmclhip_v_*.so variant build (kernel time of the sector query), three rounds.
+for round in 1 2 3; do
 for f in slam_amd/libmclhip_v_*.so; do
   n=$(basename $f)
-  MCLHIP_LIBNAME=$n timeout -k 10 300 python bench.py --steps 10 --cpu-particles 0 > gpurun_out/v.json 2> gpurun_out/v.err || exit 1
+  MCLHIP_LIBNAME=$n timeout -k 10 300 python bench.py --steps 30 --cpu-particles 0 > gpurun_out/v.json 2> gpurun_out/v.err || exit 1
   python -c "import json; d=json.load(open('gpurun_out/v.json')); print('$n', round(d['kernel_ms']['raycast'],4), round(d['ms_per_step'],4))"
+done
 done
