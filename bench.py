@@ -83,7 +83,7 @@ def profiled_traffic(args):
         return None
     d = json.load(open(files[-1]))
     for name, ctr in d.items():
-        if "raycast_kernel<float, false, false>" in name and "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
+        if "raycast_kernel<float, false, false" in name and "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
             return (2.0 * ctr["FETCH_SIZE"]["per_launch_mean"] + ctr["WRITE_SIZE"]["per_launch_mean"]) * 1024.0
     return None
 

@@ -135,7 +135,7 @@ __device__ __attribute__((noinline)) double slow_log(double v) { return log(v); 
 #define MCL_RAY_WAVES 6
 #endif
 template <typename T, bool STAGE, bool PRODUCT, bool GRID = false>
-__global__ __launch_bounds__(256, MCL_RAY_WAVES) void raycast_kernel(
+__global__ __launch_bounds__(256, (sizeof(T) == 4 ? MCL_RAY_WAVES : 4)) void raycast_kernel(
     RayParams P, const T* __restrict__ xs, const T* __restrict__ ys, const T* __restrict__ ths,
     const uint8_t* __restrict__ pm, int64_t n, double* __restrict__ w_out, double* __restrict__ logw_out,
     double* __restrict__ ranges_out, int32_t* __restrict__ hits_out) {
