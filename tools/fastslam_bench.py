@@ -16,7 +16,22 @@ for t in range(steps):
     slam.control(ut)
     t_all.append(time.perf_counter() - t0)
     print("step", t, "%.1f ms" % (t_all[-1] * 1e3), flush=True)
-st_n = slam._ctx.fs_get_state()["nfeat"] if M <= (1 << 18) else None
+st = slam._ctx.fs_get_state() if M <= (1 << 18) else None
 ms = float(np.median(t_all[1:])) * 1e3
-print({"particles": M, "landmarks": NL, "ms_per_step_median": ms, "particle_steps_per_s": M / (ms * 1e-3),
-       "mean_features": None if st_n is None else float(st_n.mean())})
+out = {"metric": "FastSLAM 1.0 particle-steps per second", "particles": M, "landmarks": NL, "value": M / (ms * 1e-3),
+       "unit": "particle-steps/s", "ms_per_step": ms, "mean_features": None if st is None else float(st["nfeat"].mean())}
+if os.environ.get("FS_CPU", "1") == "1":
+    # CPU baseline: the numpy restatement on 64 particles of the same landmark field (one core)
+    from oracle import fastslam_oracle as F
+    orc = F.OracleFastSLAM(64, lm)
+    rs = np.random.RandomState(1)
+    tt = []
+    for t in range(4):
+        ut = [25, 0.001]
+        nv = sum(1 for a in F.true_measurements(F.true_pose_step(orc.x_gt, ut), lm) if a[2])
+        ints = rs.randint(-1000, 1000, size=(64, 3, 12)); nrm = rs.randn(64, 2 * nv)
+        t0 = time.perf_counter(); orc.step(ut, ints, nrm, rs.rand()); tt.append(time.perf_counter() - t0)
+    out["cpu_baseline"] = {"value": 64 / tt[-1], "unit": "particle-steps/s", "cores": 1, "kind": "port",
+                           "sample": "64 particles x %d landmarks, fourth step in %.2f s" % (NL, tt[-1])}
+import json
+print(json.dumps(out))

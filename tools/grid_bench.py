@@ -21,6 +21,26 @@ for t in range(steps):
     print("step", t, "sum", s, flush=True)
 np_, msp = ctx.timing_get(3); nu, msu = ctx.timing_get(4)
 cells = N * N
-print({"grid": [N, N, D], "predict_ms": msp / max(np_, 1), "update_ms": msu / max(nu, 1),
-       "predict_GFLOPs": 2.0 * cells * D * D * 49 / (msp / max(np_, 1) * 1e-3) / 1e9,
-       "update_cell_heading_beams_per_s": cells * D * 13 / (msu / max(nu, 1) * 1e-3)})
+pred_ms, upd_ms = msp / max(np_, 1), msu / max(nu, 1)
+free = int(np.count_nonzero(grid >= 200))
+evals = free * D * 13                      # (cell, heading, beam) sector evaluations of one update
+out = {"metric": "grid localisation: (cell, heading) poses per second, predict + update", "grid": [N, N, D],
+       "value": cells * D / ((pred_ms + upd_ms) * 1e-3), "unit": "poses/s", "predict_ms": pred_ms, "update_ms": upd_ms,
+       "roofline": {"kernel": "raycast_kernel GRID mode (update)", "bound": "hbm", "unit": "GB/s", "peak": 8000.0,
+                    "achieved": 97.2 * evals / (upd_ms * 1e-3) / 1e9, "frac": 97.2 * evals / (upd_ms * 1e-3) / 1e9 / 8000.0,
+                    "algorithmic_bytes_per_eval": 97.2, "traffic": None},
+       "predict_roofline": {"kernel": "grid_predict_kernel", "bound": "fp64 vector FMA (dense 7x7xDxD contraction)",
+                            "unit": "TFLOP/s", "peak": 78.6, "achieved": 2.0 * cells * D * D * 49 / (pred_ms * 1e-3) / 1e12,
+                            "frac": 2.0 * cells * D * D * 49 / (pred_ms * 1e-3) / 1e12 / 78.6}}
+if os.environ.get("GRID_CPU", "1") == "1":
+    # CPU baseline: the numpy restatement on the reference's own 100x100x4 problem (one core)
+    from oracle import grid_oracle as G
+    g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "grid_seed0.npz"))
+    t0 = time.perf_counter()
+    pp = G.predict(g["s0_pk_in"], g["map"], (1.5, 0), 4)
+    G.update(pp, g["map"], [float(v) for v in g["s0_z_meas"]], 4)
+    dtc = time.perf_counter() - t0
+    out["cpu_baseline"] = {"value": 100 * 100 * 4 / dtc, "unit": "poses/s", "cores": 1, "kind": "port",
+                           "sample": "reference configuration 100x100 cells x 4 headings, one predict + update in %.1f s" % dtc}
+import json
+print(json.dumps(out))
