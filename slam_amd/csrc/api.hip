@@ -48,7 +48,7 @@ RayParams make_ray_params(const mclhip_ctx* c) {
   P.p_rand = 1 / c->z_max;                               // range_sensor.py:64
   P.range_noise = nullptr;
   P.stamps = c->stamps;
-  P.g_cell = nullptr; P.g_pk_pred = nullptr; P.g_pk = nullptr; P.g_D = 0; P.g_B0 = 0;
+  P.g_cell = nullptr; P.g_inv_perm = nullptr; P.g_pk_pred = nullptr; P.g_pk = nullptr; P.g_D = 0; P.g_B0 = 0;
   P.no_obstacles = c->n_obstacles == 0 ? 1 : 0;
   return P;
 }
@@ -277,7 +277,7 @@ void mclhip_destroy(mclhip_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   fs_release(c);
-  void* ptrs[] = {c->obst, c->freeb, c->tile_off, c->cells, c->nbr_off, c->nbr_cells, c->tab_sorted, c->tab_orig, c->perm, c->lut, c->relx, c->zt, c->etalam, c->zmeas_stage, c->ring,
+  void* ptrs[] = {c->obst, c->freeb, c->tile_off, c->cells, c->nbr_off, c->nbr_cells, c->tab_sorted, c->tab_orig, c->perm, c->inv_perm, c->lut, c->relx, c->zt, c->etalam, c->zmeas_stage, c->ring,
                   c->px[0], c->px[1], c->py[0], c->py[1], c->pth[0], c->pth[1], c->w[0], c->w[1], c->logw, c->pm,
                   c->sx, c->sy, c->sth, c->sw, c->chunk_sums, c->scal, c->cdf_approx, c->cdf_exact, c->kscan,
                   c->fscan, c->blk_a, c->blk_b, c->irr, c->bases, c->idx, c->noise, c->counters, c->range_noise, c->inj_rows, c->stamps,
@@ -397,6 +397,7 @@ int mcl::set_sensor_table(mclhip_ctx* c, const double* tab_rad, int B, double z_
   MCL_TRY(dev_alloc(c, &c->tab_sorted, B * sizeof(double)));
   MCL_TRY(dev_alloc(c, &c->tab_orig, B * sizeof(double)));
   MCL_TRY(dev_alloc(c, &c->perm, B * sizeof(uint16_t)));
+  MCL_TRY(dev_alloc(c, &c->inv_perm, B * sizeof(uint16_t)));
   MCL_TRY(dev_alloc(c, &c->lut, NB * sizeof(uint16_t)));
   MCL_TRY(dev_alloc(c, &c->zt, B * sizeof(double)));
   MCL_TRY(dev_alloc(c, &c->etalam, B * sizeof(double)));
@@ -404,6 +405,11 @@ int mcl::set_sensor_table(mclhip_ctx* c, const double* tab_rad, int B, double z_
   MCL_HIP(c, hipMemcpy(c->tab_sorted, ts.data(), B * sizeof(double), hipMemcpyHostToDevice));
   MCL_HIP(c, hipMemcpy(c->tab_orig, tab.data(), B * sizeof(double), hipMemcpyHostToDevice));
   MCL_HIP(c, hipMemcpy(c->perm, perm.data(), B * sizeof(uint16_t), hipMemcpyHostToDevice));
+  {
+    std::vector<uint16_t> inv(B);
+    for (int k = 0; k < B; ++k) inv[perm[k]] = (uint16_t)k;
+    MCL_HIP(c, hipMemcpy(c->inv_perm, inv.data(), B * sizeof(uint16_t), hipMemcpyHostToDevice));
+  }
   MCL_HIP(c, hipMemcpy(c->lut, lut.data(), NB * sizeof(uint16_t), hipMemcpyHostToDevice));
   MCL_HIP(c, hipMemset(c->zt, 0, B * sizeof(double)));
   MCL_HIP(c, hipMemset(c->etalam, 0, B * sizeof(double)));

@@ -56,6 +56,7 @@ struct RayParams {
   unsigned long long* stamps;  // profiling build only: cycles per kernel section
   // histogram-filter update (one pose per free grid cell)
   const int32_t* g_cell;       // flat cell index of pose p
+  const uint16_t* g_inv_perm;  // sorted-table position of caller-order entry e
   const double* g_pk_pred;     // [H*W*D]
   float* g_pk;                 // [H*W*D]
   int g_D, g_B0;               // headings, beams per heading
@@ -99,6 +100,7 @@ struct mclhip_ctx {
   double* tab_sorted = nullptr;
   double* tab_orig = nullptr;
   uint16_t* perm = nullptr;
+  uint16_t* inv_perm = nullptr;
   uint16_t* lut = nullptr;
   float* relx = nullptr;
   int G = 0;

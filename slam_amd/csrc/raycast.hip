@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? MCL_RAY_WAVES : 4)) void ray
   unsigned long long* s_rmin_all = reinterpret_cast<unsigned long long*>(s_el + B);
   const int NXP = P.G + B + kGroup;                              // extended table + one group of padding
   unsigned long long* s_aux_all = s_rmin_all + (size_t)kWavesPerBlock * NXP;
-  unsigned int* s_walk_all = reinterpret_cast<unsigned int*>(s_aux_all + (size_t)((STAGE || PRODUCT || GRID) ? kWavesPerBlock * NXP : 0));
+  unsigned int* s_walk_all = reinterpret_cast<unsigned int*>(s_aux_all + (size_t)((STAGE || PRODUCT) ? kWavesPerBlock * NXP : 0));
   float* s_relx = reinterpret_cast<float*>(s_walk_all + (size_t)kWavesPerBlock * kWaveScratch);  // [G + B] extended angle table
   unsigned short* s_perm = reinterpret_cast<unsigned short*>(s_relx + NXP);
   unsigned short* s_lut = s_perm + B;
@@ -407,13 +407,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? MCL_RAY_WAVES : 4)) void ray
         const double p_max = (fabs(xm - P.z_max) < 1e-6) ? 1.0 : 0.0;
         const double p_rand = in_range ? P.p_rand : 0.0;
         const double pkd = p_hit * P.w_hit + p_short * P.w_short + p_max * P.w_max + p_rand * P.w_rand;
-        aux[s_perm[k]] = (unsigned long long)__double_as_longlong(pkd);
+        rmin[G + k] = (unsigned long long)__double_as_longlong(pkd);   // in place: the minimum of entry k is spent
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       const int64_t cell = P.g_cell[p];
       for (int d = lane; d < P.g_D; d += 64) {
         double q = 1.0;   // q *= p_k in beam order (robot.py:295-298)
-        for (int k = 0; k < P.g_B0; ++k) q = q * __longlong_as_double((long long)aux[d * P.g_B0 + k]);
+        for (int k = 0; k < P.g_B0; ++k)
+          q = q * __longlong_as_double((long long)rmin[G + P.g_inv_perm[d * P.g_B0 + k]]);
         P.g_pk[cell * P.g_D + d] = (float)(P.g_pk_pred[cell * P.g_D + d] * q);   // robot.py:300, float32 store
       }
     } else {
@@ -531,8 +532,9 @@ int launch_grid_update(mclhip_ctx* c, const double* d_x, const double* d_y, cons
                        int64_t n, int n_dir, int beams_per_dir, const double* pk_pred, float* pk) {
   if (n <= 0) return MCLHIP_OK;
   RayParams P = make_ray_params(c);
+  P.g_inv_perm = c->inv_perm;
   P.g_cell = d_cell; P.g_D = n_dir; P.g_B0 = beams_per_dir; P.g_pk_pred = pk_pred; P.g_pk = pk;
-  const size_t lds = ray_lds_bytes(P.B, P.G, P.NB, P.n_ring, true);
+  const size_t lds = ray_lds_bytes(P.B, P.G, P.NB, P.n_ring, false);
   if (lds > 160 * 1024) return fail(c, MCLHIP_E_LIMIT, "heading x beam table does not fit the kernel's LDS budget");
   auto kern = raycast_kernel<double, false, false, true>;
   if (lds > 48 * 1024)
