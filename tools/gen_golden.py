@@ -204,7 +204,7 @@ def save_steps(name, rec, extra):
 
 
 def case_reference_demo():
-    """BASELINE config 1: grid_map.png, M=500, 13 beams (mc_localization.py:303-331)."""
+    """The reference demo: grid_map.png, M=500, 13 beams (mc_localization.py:303-331)."""
     map_g = load_ref_map()
     np.save(os.path.join(OUT, "grid_map_g.npy"), map_g)
     for seed in (0, 1, 2):
