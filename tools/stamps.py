@@ -1,4 +1,5 @@
-"""Profiling aid: cycles per section of the sector-query kernel (needs libmclhip_prof.so, built with -DMCL_STAMPS)."""
+"""Profiling aid: cycles per section (`make -C slam_amd/csrc stamps`) or loop trip counts (`make -C slam_amd/csrc
+counts`) of the sector-query kernel; either target writes slam_amd/libmclhip_prof.so, which this script loads."""
 import os, sys
 os.environ["MCLHIP_LIBNAME"] = "libmclhip_prof.so"
 import numpy as np
