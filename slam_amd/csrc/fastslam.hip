@@ -145,9 +145,9 @@ __global__ __launch_bounds__(128) void fs_step_kernel(FsParams P) {
   // ---- every landmark: draw the measurement, associate, create or update (:286-375) ----
   // The association of a measurement reads only what the prediction pass stored (z_pred, invQ,
   // det Q of the features that existed before this step), never what an earlier measurement of
-  // the same step changed.  So eight measurements are associated together -- one sweep over the
-  // stored features serves all eight -- and then applied one by one in landmark order.
-  constexpr int kChunk = 8;
+  // the same step changed.  So sixteen measurements are associated together -- one sweep over the
+  // stored features serves all sixteen (8: 29 ms, 16: 26 ms at 2^20 x 256) -- and then applied one by one in landmark order.
+  constexpr int kChunk = 16;
   int used = 0;
   int l = 0;
   while (l < P.L) {
