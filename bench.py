@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--regime", default="global", choices=["global", "tracking"],
                     help="global: every step starts from the uniform synthetic cloud; tracking: the filter runs on")
     ap.add_argument("--cpu-particles", type=int, default=8192, help="particles of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--host-collectives", action="store_true",
+                    help="multi-rank step with the host combining the ranks' small results (default: device-driven)")
     ap.add_argument("--rehearse-collectives", action="store_true",
                     help="run the multi-rank code path (RCCL group, cross-rank resampling) even with one rank")
     return ap.parse_args()
@@ -136,7 +138,8 @@ def main():
     rs = np.random.RandomState(W.SEED_STREAM)
     r_draw = rs.rand(n_total) / (M * world)
     alpha = [4, 2, 4, 4, 4, 2]
-    filt = ShardedFilter(ctx, dist, rank, world, M, force_collectives=a.rehearse_collectives)
+    filt = ShardedFilter(ctx, dist, rank, world, M, force_collectives=a.rehearse_collectives,
+                         device_path=False if a.host_collectives else None)
 
     def one_step(t):
         if a.regime == "global":
@@ -190,7 +193,9 @@ def main():
                                    "%s state, device noise, log-weights, regime=%s"
                                    % (M, B, a.map, a.map, 100.0 * float(np.mean(grid == 0)), a.dtype, a.regime),
                        "particles_per_gpu": M, "beams": B, "map": a.map, "regime": a.regime,
-                       "sharding": "contiguous particle ranges, map replicated" if world > 1 else "single GPU"},
+                       "sharding": ("contiguous particle ranges, map replicated; %s" %
+                                    ("device-driven exchange" if filt.device_path else "host-combined exchange"))
+                       if filt.collective else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": profiled_traffic(a),
                          "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, profiles/)",

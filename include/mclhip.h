@@ -223,6 +223,38 @@ int mclhip_shard_pack(mclhip_ctx* ctx, const int64_t* lo, const int64_t* hi, int
 int mclhip_shard_unpack_resample(mclhip_ctx* ctx, const void* rows, int64_t L, double r, int64_t row0_global,
                                  int64_t* idx_out);
 
+/* Device-driven variant of the multi-GPU step.  No counterpart in the reference
+ * (it is single-process).  Same arithmetic as the mclhip_shard_* calls above, but
+ * every call only enqueues on the context's stream and exchanges data through
+ * DEVICE pointers (e.g. torch tensors that RCCL collectives read and write), so a
+ * whole step needs one device-to-host read.  Log-weight mode only.
+ * firsts [world + 1]: global index of every rank's first particle, firsts[world]
+ * = total.  cap: irregular records per rank that fit the exchange block of
+ * 16 + 24 * cap bytes. */
+
+/* Run the context on a caller's HIP stream (NULL: back to its own). */
+int mclhip_set_stream(mclhip_ctx* ctx, void* hip_stream);
+/* motion + sector query + likelihood, then the local maximum log-weight -> *d_max_out. */
+int mclhip_dshard_sample_max(mclhip_ctx* ctx, double v, double omega, double dt, const double alpha[6],
+                             const int16_t* noise_ints, uint64_t seed, const double* z_meas, int weight_mode,
+                             double* d_max_out);
+/* w = exp(logw - *d_gmax); this rank's 8192-element chunk sums -> d_chunks_out. */
+int mclhip_dshard_weights(mclhip_ctx* ctx, const double* d_gmax, double* d_chunks_out);
+/* d_all_chunks [world][cmax] (cmax = largest chunk count of a rank): global sum in
+ * rank order, normalisation, local scan; header + records -> d_records_out. */
+int mclhip_dshard_scan(mclhip_ctx* ctx, const double* d_all_chunks, const int64_t* firsts, int world, int rank,
+                       void* d_records_out, int cap);
+/* d_all_records [world][16 + 24*cap bytes]: global record list, exact local running
+ * sums; d_counts_out [2*world + 1]: local counts below U of every rank's first and
+ * last position (to be summed over ranks), last entry = 1 if a rank overflowed cap. */
+int mclhip_dshard_finalize(mclhip_ctx* ctx, const void* d_all_records, const int64_t* firsts, int world, int rank,
+                           int cap, double r, int64_t* d_counts_out);
+/* as mclhip_shard_pack / mclhip_shard_unpack_resample, rows on the device, no wait. */
+int mclhip_dshard_pack(mclhip_ctx* ctx, const int64_t* lo, const int64_t* hi, int nslices, void* d_rows);
+int mclhip_dshard_unpack_resample(mclhip_ctx* ctx, const void* d_rows, int64_t L, double r, int64_t row0_global);
+/* Ancestor indices of the last resampling (waits for the stream). */
+int mclhip_get_indices(mclhip_ctx* ctx, int64_t* idx_out);
+
 /* Grid (histogram) localisation -- robot.py / grid_localization.py (Table 8.1) --
  * on the same context.  The belief lives on the device as float32 [H][W][D]
  * (the reference keeps float32, robot.py:49-60), the prediction as float64. */

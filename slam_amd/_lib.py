@@ -66,6 +66,16 @@ PROTOTYPES = {
     "mclhip_shard_count_below": (C.c_int, [_ctx_p, _dbl_p, C.c_int, _i64_p]),
     "mclhip_shard_pack": (C.c_int, [_ctx_p, _i64_p, _i64_p, C.c_int, C.c_void_p]),
     "mclhip_shard_unpack_resample": (C.c_int, [_ctx_p, C.c_void_p, C.c_int64, C.c_double, C.c_int64, _i64_p]),
+    "mclhip_set_stream": (C.c_int, [_ctx_p, C.c_void_p]),
+    "mclhip_dshard_sample_max": (C.c_int, [_ctx_p, C.c_double, C.c_double, C.c_double, _dbl_p, _i16_p, C.c_uint64,
+                                           _dbl_p, C.c_int, C.c_void_p]),
+    "mclhip_dshard_weights": (C.c_int, [_ctx_p, C.c_void_p, C.c_void_p]),
+    "mclhip_dshard_scan": (C.c_int, [_ctx_p, C.c_void_p, _i64_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "mclhip_dshard_finalize": (C.c_int, [_ctx_p, C.c_void_p, _i64_p, C.c_int, C.c_int, C.c_int, C.c_double,
+                                         C.c_void_p]),
+    "mclhip_dshard_pack": (C.c_int, [_ctx_p, _i64_p, _i64_p, C.c_int, C.c_void_p]),
+    "mclhip_dshard_unpack_resample": (C.c_int, [_ctx_p, C.c_void_p, C.c_int64, C.c_double, C.c_int64]),
+    "mclhip_get_indices": (C.c_int, [_ctx_p, _i64_p]),
     "mclhip_grid_set_map": (C.c_int, [_ctx_p, _u8_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]),
     "mclhip_grid_set_sensor": (C.c_int, [_ctx_p, _dbl_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                          C.c_double, _dbl_p, C.c_double]),
@@ -348,6 +358,47 @@ class Context:
         self._ck(self.lib.mclhip_shard_unpack_resample(self.h, C.c_void_p(rows_ptr), int(L), float(r),
                                                        int(row0_global), _p(idx, _i64_p)),
                  "mclhip_shard_unpack_resample")
+        return idx
+
+    # device-driven multi-GPU step (device pointers in, nothing waits) ---------
+    def set_stream(self, hip_stream):
+        self._ck(self.lib.mclhip_set_stream(self.h, C.c_void_p(hip_stream or 0)), "mclhip_set_stream")
+
+    def dshard_sample_max(self, v, omega, dt, alpha, z_meas, noise_ints, seed, mode, d_max):
+        al = _f64(alpha, (6,))
+        z = _f64(z_meas)
+        if noise_ints is not None:
+            noise_ints = np.ascontiguousarray(noise_ints, dtype=np.int16)
+        self._ck(self.lib.mclhip_dshard_sample_max(self.h, float(v), float(omega), float(dt), _p(al, _dbl_p),
+                                                   _p(noise_ints, _i16_p), int(seed), _p(z, _dbl_p), int(mode),
+                                                   C.c_void_p(d_max)), "mclhip_dshard_sample_max")
+
+    def dshard_weights(self, d_gmax, d_chunks):
+        self._ck(self.lib.mclhip_dshard_weights(self.h, C.c_void_p(d_gmax), C.c_void_p(d_chunks)), "mclhip_dshard_weights")
+
+    def dshard_scan(self, d_all_chunks, firsts, rank, d_records, cap):
+        f = np.ascontiguousarray(firsts, np.int64)
+        self._ck(self.lib.mclhip_dshard_scan(self.h, C.c_void_p(d_all_chunks), _p(f, _i64_p), len(f) - 1, int(rank),
+                                             C.c_void_p(d_records), int(cap)), "mclhip_dshard_scan")
+
+    def dshard_finalize(self, d_all_records, firsts, rank, cap, r, d_counts):
+        f = np.ascontiguousarray(firsts, np.int64)
+        self._ck(self.lib.mclhip_dshard_finalize(self.h, C.c_void_p(d_all_records), _p(f, _i64_p), len(f) - 1, int(rank),
+                                                 int(cap), float(r), C.c_void_p(d_counts)), "mclhip_dshard_finalize")
+
+    def dshard_pack(self, lo, hi, d_rows):
+        lo = np.ascontiguousarray(lo, np.int64)
+        hi = np.ascontiguousarray(hi, np.int64)
+        self._ck(self.lib.mclhip_dshard_pack(self.h, _p(lo, _i64_p), _p(hi, _i64_p), len(lo), C.c_void_p(d_rows)),
+                 "mclhip_dshard_pack")
+
+    def dshard_unpack_resample(self, d_rows, L, r, row0_global):
+        self._ck(self.lib.mclhip_dshard_unpack_resample(self.h, C.c_void_p(d_rows), int(L), float(r), int(row0_global)),
+                 "mclhip_dshard_unpack_resample")
+
+    def get_indices(self):
+        idx = np.empty(self.num_particles(), np.int64)
+        self._ck(self.lib.mclhip_get_indices(self.h, _p(idx, _i64_p)), "mclhip_get_indices")
         return idx
 
     # grid (histogram) localisation ------------------------------------------

@@ -260,6 +260,7 @@ int mclhip_create(mclhip_ctx** out, int device, int dtype) {
   c->dtype = dtype;
   e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  c->own_stream = c->stream;
   if (e == hipSuccess) e = hipMalloc((void**)&c->scal, 8 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&c->stamps, 16 * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMemset(c->stamps, 0, 16 * sizeof(unsigned long long));
@@ -285,7 +286,7 @@ void mclhip_destroy(mclhip_ctx* c) {
                   c->rows_send, c->rows_recv, c->small_d, c->small_i};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
 
@@ -827,6 +828,129 @@ int mclhip_shard_count_below(mclhip_ctx* c, const double* U, int n, int64_t* cou
   MCL_TRY(launch_count_below(c, c->small_d, n, c->small_i));
   MCL_HIP(c, hipMemcpyAsync(counts_out, c->small_i, n * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
   MCL_HIP(c, hipStreamSynchronize(c->stream));
+  return MCLHIP_OK;
+}
+
+// ---- device-driven cross-rank path: every call below only enqueues on the context's stream ----
+
+int mclhip_set_stream(mclhip_ctx* c, void* stream) {
+  MCL_TRY(use(c));
+  MCL_HIP(c, hipStreamSynchronize(c->stream));
+  c->stream = stream ? (hipStream_t)stream : c->own_stream;
+  return MCLHIP_OK;
+}
+
+static int make_layout(mclhip_ctx* c, ShardLayout& lay, const int64_t* firsts, int world, int rank) {
+  if (!firsts || world < 1 || world > 64 || rank < 0 || rank >= world) return fail(c, MCLHIP_E_ARG, "firsts NULL or world/rank outside 1..64");
+  lay.world = world; lay.rank = rank; lay.cmax = 0;
+  for (int r = 0; r < world; ++r) {
+    if (firsts[r + 1] < firsts[r]) return fail(c, MCLHIP_E_ARG, "firsts must ascend");
+    lay.first[r] = firsts[r];
+    lay.nchunks[r] = (int)((firsts[r + 1] - firsts[r] + kSumChunk - 1) / kSumChunk);
+    lay.cmax = std::max(lay.cmax, lay.nchunks[r]);
+  }
+  lay.first[world] = firsts[world];
+  if (firsts[rank + 1] - firsts[rank] != c->M || firsts[rank] != c->first_index || firsts[world] != c->m_total)
+    return fail(c, MCLHIP_E_STATE, "firsts disagree with mclhip_shard_set / the local particle count");
+  return MCLHIP_OK;
+}
+
+int mclhip_dshard_sample_max(mclhip_ctx* c, double v, double omega, double dt, const double alpha[6],
+                             const int16_t* noise_ints, uint64_t seed, const double* z_meas, int weight_mode,
+                             double* d_max_out) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, true, true, true));
+  if (!alpha || !d_max_out) return fail(c, MCLHIP_E_ARG, "alpha or d_max_out is NULL");
+  MCL_TRY(upload_zmeas(c, z_meas));
+  if (noise_ints) MCL_TRY(upload_noise(c, noise_ints));
+  MCL_TRY(enqueue_sample(c, v, omega, dt, alpha, noise_ints ? 1 : 2, seed, c->spans, weight_mode == MCLHIP_W_PRODUCT));
+  span_begin(c, c->spans, 2);
+  MCL_TRY(launch_shard_max_logw(c));
+  span_end(c, c->spans);
+  MCL_HIP(c, hipMemcpyAsync(d_max_out, c->scal + 1, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  return MCLHIP_OK;
+}
+
+int mclhip_dshard_weights(mclhip_ctx* c, const double* d_gmax, double* d_chunks_out) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, false, false, true));
+  if (!d_gmax || !d_chunks_out) return fail(c, MCLHIP_E_ARG, "device pointer is NULL");
+  const int64_t nch = (c->M + kSumChunk - 1) / kSumChunk;
+  MCL_HIP(c, hipMemcpyAsync(c->scal + 1, d_gmax, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  span_begin(c, c->spans, 2);
+  MCL_TRY(launch_dshard_weights(c));
+  span_end(c, c->spans);
+  MCL_HIP(c, hipMemcpyAsync(d_chunks_out, c->chunk_sums, nch * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  return MCLHIP_OK;
+}
+
+int mclhip_dshard_scan(mclhip_ctx* c, const double* d_all_chunks, const int64_t* firsts, int world, int rank,
+                       void* d_records_out, int cap) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, false, false, true));
+  if (!d_all_chunks || !d_records_out || cap < 1) return fail(c, MCLHIP_E_ARG, "device pointer NULL or cap < 1");
+  if (c->m_total <= 0) return fail(c, MCLHIP_E_STATE, "call mclhip_shard_set first");
+  ShardLayout lay;
+  MCL_TRY(make_layout(c, lay, firsts, world, rank));
+  span_begin(c, c->spans, 2);
+  MCL_TRY(launch_dshard_scan(c, d_all_chunks, lay, d_records_out, cap));
+  span_end(c, c->spans);
+  return MCLHIP_OK;
+}
+
+int mclhip_dshard_finalize(mclhip_ctx* c, const void* d_all_records, const int64_t* firsts, int world, int rank,
+                           int cap, double r, int64_t* d_counts_out) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, false, false, true));
+  if (!d_all_records || !d_counts_out || cap < 1) return fail(c, MCLHIP_E_ARG, "device pointer NULL or cap < 1");
+  ShardLayout lay;
+  MCL_TRY(make_layout(c, lay, firsts, world, rank));
+  const int64_t n_all = (int64_t)world * cap;
+  if (n_all > c->g_records_cap) {
+    MCL_HIP(c, hipStreamSynchronize(c->stream));
+    MCL_TRY(dev_alloc(c, &c->g_records, (size_t)n_all * irr_record_bytes()));
+    MCL_TRY(dev_alloc(c, &c->g_bases, (size_t)n_all * run_base_bytes()));
+    c->g_records_cap = n_all;
+  }
+  if (!c->small_i) MCL_TRY(dev_alloc(c, &c->small_i, 1024 * sizeof(int64_t)));
+  span_begin(c, c->spans, 2);
+  MCL_TRY(launch_dshard_finalize(c, d_all_records, lay, cap, r, d_counts_out));
+  span_end(c, c->spans);
+  return MCLHIP_OK;
+}
+
+int mclhip_dshard_pack(mclhip_ctx* c, const int64_t* lo, const int64_t* hi, int nslices, void* d_rows) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, false, false, true));
+  if (!lo || !hi || nslices <= 0) return fail(c, MCLHIP_E_ARG, "lo/hi NULL or no slices");
+  int64_t off = 0;
+  span_begin(c, c->spans, 2);
+  for (int s = 0; s < nslices; ++s) {
+    if (lo[s] < 0 || hi[s] > c->M || hi[s] < lo[s]) return fail(c, MCLHIP_E_ARG, "slice outside the local range");
+    if (hi[s] > lo[s] && !d_rows) return fail(c, MCLHIP_E_ARG, "d_rows is NULL");
+    MCL_TRY(launch_pack_rows(c, lo[s], hi[s], (double*)d_rows + off * 5));
+    off += hi[s] - lo[s];
+  }
+  span_end(c, c->spans);
+  return MCLHIP_OK;
+}
+
+int mclhip_dshard_unpack_resample(mclhip_ctx* c, const void* d_rows, int64_t L, double r, int64_t row0_global) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, false, false, true));
+  if (!d_rows || L <= 0) return fail(c, MCLHIP_E_ARG, "d_rows NULL or empty");
+  span_begin(c, c->spans, 2);
+  MCL_TRY(launch_unpack_resample(c, (const double*)d_rows, L, c->first_index, c->m_total, r, row0_global));
+  span_end(c, c->spans);
+  return MCLHIP_OK;
+}
+
+int mclhip_get_indices(mclhip_ctx* c, int64_t* idx_out) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, false, false, true));
+  if (!idx_out) return fail(c, MCLHIP_E_ARG, "idx_out is NULL");
+  MCL_HIP(c, hipStreamSynchronize(c->stream));
+  MCL_HIP(c, hipMemcpy(idx_out, c->idx, c->M * sizeof(int64_t), hipMemcpyDeviceToHost));
   return MCLHIP_OK;
 }
 

@@ -79,6 +79,7 @@ struct mclhip_ctx {
   int device = 0;
   int dtype = MCLHIP_F64;
   hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr;   // the stream the context created (stream may be a caller's)
   std::string err;
 
   // map
@@ -212,9 +213,17 @@ int launch_normalise(mclhip_ctx* c, int mode);
 int launch_resample(mclhip_ctx* c, double r, int algo);
 int launch_shard_max_logw(mclhip_ctx* c);
 int launch_shard_weights(mclhip_ctx* c, int mode, double gmax);
-int launch_shard_scan(mclhip_ctx* c, double total, double approx_offset, int64_t first_index);
+int launch_dshard_weights(mclhip_ctx* c);
+int launch_shard_scan(mclhip_ctx* c, double total, double approx_offset, int64_t first_index, const double* d_offset = nullptr);
+struct ShardLayout {   // who holds what of the global particle vector (at most 64 ranks)
+  int world, rank, cmax;
+  int nchunks[64];       // 8192-element chunks per rank
+  int64_t first[65];     // global index of every rank's first particle; first[world] = total
+};
+int launch_dshard_scan(mclhip_ctx* c, const double* d_all_chunks, const ShardLayout& lay, void* d_rec_out, int cap);
+int launch_dshard_finalize(mclhip_ctx* c, const void* d_all_rec, const ShardLayout& lay, int cap, double r, int64_t* d_counts);
 int launch_shard_finalize(mclhip_ctx* c, const void* d_records, int64_t nrec, void* d_bases, uint64_t P_off,
-                          uint32_t F_off);
+                          uint32_t F_off, const unsigned long long* d_meta = nullptr);
 int launch_count_below(mclhip_ctx* c, const double* d_U, int nu, int64_t* d_counts);
 int launch_pack_rows(mclhip_ctx* c, int64_t lo, int64_t hi, double* d_dst);
 int launch_unpack_resample(mclhip_ctx* c, const double* d_rows, int64_t L, int64_t first_index, int64_t m_total,

@@ -250,8 +250,10 @@ struct ClassifyLoader {
   const double* ca;  // approximate inclusive scan of the local wn
   const double* wn;
   int64_t i0;        // global index of local element 0 (0 on a single GPU)
-  double off;        // approximate running sum of everything before local element 0
+  double off_value;  // approximate running sum of everything before local element 0 ...
+  const double* off_ptr;   // ... or where to read it on the device (when not NULL)
   __device__ KF operator()(int64_t il) const {
+    const double off = off_ptr ? *off_ptr : off_value;
     const double w = wn[il];
     const int64_t i = i0 + il;
     if (i == 0) return KF{0ull, 1u};
@@ -300,9 +302,10 @@ struct StoreKF {
 // One wavefront walks the irregular elements in order.
 __global__ __launch_bounds__(64) void replay_kernel(const IrrRecord* __restrict__ irr,
                                                     const unsigned int* __restrict__ fs, int64_t n,
-                                                    int64_t nirr_given, RunBase* __restrict__ bases) {
+                                                    int64_t nirr_given, RunBase* __restrict__ bases,
+                                                    const unsigned long long* __restrict__ nirr_ptr) {
   const int lane = threadIdx.x;
-  const unsigned int nirr = fs ? fs[n - 1] : (unsigned int)nirr_given;
+  const unsigned int nirr = nirr_ptr ? (unsigned int)nirr_ptr[0] : (fs ? fs[n - 1] : (unsigned int)nirr_given);
   double c = 0.0;
   unsigned long long Pprev = 0ull;
   int e_run = -1000;
@@ -327,9 +330,11 @@ __global__ __launch_bounds__(64) void replay_kernel(const IrrRecord* __restrict_
 
 __global__ void finalize_cdf_kernel(const unsigned long long* __restrict__ ks, const unsigned int* __restrict__ fs,
                                     const RunBase* __restrict__ bases, int64_t n, unsigned long long P_off,
-                                    unsigned int F_off, double* __restrict__ cdf) {
+                                    unsigned int F_off, double* __restrict__ cdf,
+                                    const unsigned long long* __restrict__ off_ptr) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (off_ptr) { P_off = off_ptr[1]; F_off = (unsigned int)off_ptr[2]; }   // offsets computed on the device
   const RunBase b = bases[F_off + fs[i] - 1];
   cdf[i] = b.c + (double)(P_off + ks[i] - b.P) * ldexp(1.0, b.e - 52);  // exact
 }
@@ -405,7 +410,7 @@ static int build_exact_cdf(mclhip_ctx* c, const double* wn, int64_t n) {
   hipLaunchKernelGGL((scan_apply_kernel<double, LoadF64, StoreF64>), dim3(ntile), dim3(kScanBlock), 0, c->stream,
                      lf, sf, n, (const double*)c->blk_a);
   // integer increments + irregular flags, scanned together
-  ClassifyLoader cl{c->cdf_approx, wn, 0, 0.0};
+  ClassifyLoader cl{c->cdf_approx, wn, 0, 0.0, nullptr};
   StoreKF sk{(unsigned long long*)c->kscan, c->fscan, (IrrRecord*)c->irr, wn, 0};
   hipLaunchKernelGGL((scan_reduce_kernel<KF, ClassifyLoader>), dim3(ntile), dim3(kScanBlock), 0, c->stream, cl, n,
                      (KF*)c->blk_b);
@@ -413,9 +418,9 @@ static int build_exact_cdf(mclhip_ctx* c, const double* wn, int64_t n) {
   hipLaunchKernelGGL((scan_apply_kernel<KF, ClassifyLoader, StoreKF>), dim3(ntile), dim3(kScanBlock), 0, c->stream,
                      cl, sk, n, (const KF*)c->blk_b);
   hipLaunchKernelGGL(replay_kernel, dim3(1), dim3(64), 0, c->stream, (const IrrRecord*)c->irr, c->fscan, n,
-                     (int64_t)0, (RunBase*)c->bases);
+                     (int64_t)0, (RunBase*)c->bases, (const unsigned long long*)nullptr);
   hipLaunchKernelGGL(finalize_cdf_kernel, dim3(g), dim3(256), 0, c->stream, (const unsigned long long*)c->kscan,
-                     c->fscan, (const RunBase*)c->bases, n, 0ull, 0u, c->cdf_exact);
+                     c->fscan, (const RunBase*)c->bases, n, 0ull, 0u, c->cdf_exact, (const unsigned long long*)nullptr);
   MCL_HIP(c, hipGetLastError());
   return MCLHIP_OK;
 }
@@ -485,13 +490,28 @@ int launch_shard_weights(mclhip_ctx* c, int mode, double gmax) {
   return MCLHIP_OK;
 }
 
+// log-mode weights with the global maximum already in scal[1] (device-driven path)
+int launch_dshard_weights(mclhip_ctx* c) {
+  const int64_t n = c->M;
+  double* w = c->w[c->cur];
+  const unsigned g = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(exp_shift_kernel, dim3(g), dim3(256), 0, c->stream, c->logw, w, n, (const double*)c->scal);
+  const int nchunks = (int)((n + kSumChunk - 1) / kSumChunk);
+  hipLaunchKernelGGL(chunk_sum_kernel, dim3(nchunks), dim3(512), 0, c->stream, w, n, c->chunk_sums);
+  MCL_HIP(c, hipGetLastError());
+  return MCLHIP_OK;
+}
+
 // divide by the global sum, approximate scan, classification, integer scan; leaves this rank's
 // irregular records (global index, weight, LOCAL integer prefix) in c->irr
-int launch_shard_scan(mclhip_ctx* c, double total, double approx_offset, int64_t first_index) {
+int launch_shard_scan(mclhip_ctx* c, double total, double approx_offset, int64_t first_index, const double* d_offset) {
   const int64_t n = c->M;
   double* wn = c->w[c->cur];
   const unsigned g = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(divide_by_kernel, dim3(g), dim3(256), 0, c->stream, wn, n, total);
+  if (d_offset)   // device-driven path: the global sum is in scal[0], the offset behind d_offset
+    hipLaunchKernelGGL(divide_kernel, dim3(g), dim3(256), 0, c->stream, wn, n, (const double*)c->scal);
+  else
+    hipLaunchKernelGGL(divide_by_kernel, dim3(g), dim3(256), 0, c->stream, wn, n, total);
   const int ntile = (int)((n + kScanTile - 1) / kScanTile);
   LoadF64 lf{wn};
   StoreF64 sf{c->cdf_approx};
@@ -500,7 +520,7 @@ int launch_shard_scan(mclhip_ctx* c, double total, double approx_offset, int64_t
   hipLaunchKernelGGL((scan_blocks_kernel<double>), dim3(1), dim3(kScanBlock), 0, c->stream, (double*)c->blk_a, ntile);
   hipLaunchKernelGGL((scan_apply_kernel<double, LoadF64, StoreF64>), dim3(ntile), dim3(kScanBlock), 0, c->stream, lf,
                      sf, n, (const double*)c->blk_a);
-  ClassifyLoader cl{c->cdf_approx, wn, first_index, approx_offset};
+  ClassifyLoader cl{c->cdf_approx, wn, first_index, approx_offset, d_offset};
   StoreKF sk{(unsigned long long*)c->kscan, c->fscan, (IrrRecord*)c->irr, wn, first_index};
   hipLaunchKernelGGL((scan_reduce_kernel<KF, ClassifyLoader>), dim3(ntile), dim3(kScanBlock), 0, c->stream, cl, n,
                      (KF*)c->blk_b);
@@ -514,14 +534,116 @@ int launch_shard_scan(mclhip_ctx* c, double total, double approx_offset, int64_t
 // replay the GLOBAL record list (already on the device in d_records, global integer prefixes)
 // and turn this rank's integer prefixes into exact running sums
 int launch_shard_finalize(mclhip_ctx* c, const void* d_records, int64_t nrec, void* d_bases, uint64_t P_off,
-                          uint32_t F_off) {
+                          uint32_t F_off, const unsigned long long* d_meta) {
   const int64_t n = c->M;
   const unsigned g = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(replay_kernel, dim3(1), dim3(64), 0, c->stream, (const IrrRecord*)d_records,
-                     (const unsigned int*)nullptr, n, nrec, (RunBase*)d_bases);
+                     (const unsigned int*)nullptr, n, nrec, (RunBase*)d_bases, d_meta);
   hipLaunchKernelGGL(finalize_cdf_kernel, dim3(g), dim3(256), 0, c->stream, (const unsigned long long*)c->kscan,
                      c->fscan, (const RunBase*)d_bases, n, (unsigned long long)P_off, (unsigned int)F_off,
-                     c->cdf_exact);
+                     c->cdf_exact, d_meta);
+  MCL_HIP(c, hipGetLastError());
+  return MCLHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Device-driven variant of the cross-rank steps: what the host computes from gathered values in the
+// functions above is computed by small kernels here, so that one filter step needs a single
+// device-to-host read (the boundary counts that size the row exchange).
+// ---------------------------------------------------------------------------
+// scal[0] = sum of every rank's chunk sums, added left to right in rank order (== np.sum of the
+// whole weight vector); scal[5] = (sum of the chunks of the ranks before this one) / scal[0]
+__global__ void shard_totals_kernel(const double* __restrict__ all_chunks, ShardLayout lay, double* __restrict__ scal) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double t = 0.0, below = 0.0;
+  for (int r = 0; r < lay.world; ++r) {
+    if (r == lay.rank) below = t;
+    const double* src = all_chunks + (size_t)r * lay.cmax;
+    for (int j = 0; j < lay.nchunks[r]; ++j) t = t + src[j];
+  }
+  scal[0] = t;
+  scal[5] = below / t;
+}
+
+// header (integer total, record count) + the first `cap` irregular records of this rank
+__global__ void export_records_kernel(const unsigned long long* __restrict__ ks, const unsigned int* __restrict__ fs,
+                                      const IrrRecord* __restrict__ irr, int64_t n, int cap,
+                                      unsigned long long* __restrict__ out) {
+  const unsigned int nrec = fs[n - 1];
+  if (threadIdx.x == 0) { out[0] = ks[n - 1]; out[1] = nrec; }
+  IrrRecord* dst = reinterpret_cast<IrrRecord*>(out + 2);
+  const unsigned int m = nrec < (unsigned int)cap ? nrec : (unsigned int)cap;
+  for (unsigned int j = threadIdx.x; j < m; j += blockDim.x) dst[j] = irr[j];
+}
+
+// every rank's exported block -> one global record list with global integer prefixes;
+// meta[0] = records in the list, meta[1] / meta[2] = this rank's integer / record offset,
+// meta[3] = 1 when some rank had more records than fit (the caller then takes the host path)
+__global__ void merge_records_kernel(const unsigned long long* __restrict__ all, int world, int rank, int cap,
+                                     IrrRecord* __restrict__ g_records, unsigned long long* __restrict__ meta) {
+  __shared__ unsigned long long p_off[65];
+  __shared__ unsigned long long f_off[65];
+  const size_t stride = 2 + (size_t)cap * (sizeof(IrrRecord) / sizeof(unsigned long long));
+  if (threadIdx.x == 0) {
+    unsigned long long p = 0ull, f = 0ull, over = 0ull;
+    for (int s = 0; s < world; ++s) {
+      p_off[s] = p; f_off[s] = f;
+      const unsigned long long* blk = all + (size_t)s * stride;
+      p += blk[0];                  // wraps modulo 2^64 like the device prefix
+      if (blk[1] > (unsigned long long)cap) over = 1ull;
+      f += blk[1] > (unsigned long long)cap ? (unsigned long long)cap : blk[1];
+    }
+    meta[0] = f; meta[1] = p_off[rank]; meta[2] = f_off[rank]; meta[3] = over;
+  }
+  __syncthreads();
+  for (int s = 0; s < world; ++s) {
+    const unsigned long long* blk = all + (size_t)s * stride;
+    const unsigned long long nrec = blk[1] > (unsigned long long)cap ? (unsigned long long)cap : blk[1];
+    const IrrRecord* src = reinterpret_cast<const IrrRecord*>(blk + 2);
+    for (unsigned long long j = threadIdx.x; j < nrec; j += blockDim.x) {
+      IrrRecord rec = src[j];
+      rec.P = rec.P + p_off[s];
+      g_records[f_off[s] + j] = rec;
+    }
+  }
+}
+
+// counts[2d], counts[2d+1] = local running sums below U of the first / last position of rank d
+// (U = r + m / M, mc_localization.py:254); counts[2*world] = the overflow flag of the merge
+__global__ void count_edges_kernel(const double* __restrict__ cdf, int64_t n, double r, ShardLayout lay,
+                                   int64_t m_total, const unsigned long long* __restrict__ meta,
+                                   int64_t* __restrict__ counts) {
+  const int j = threadIdx.x;
+  if (j == 2 * lay.world) { counts[j] = (int64_t)meta[3]; return; }
+  if (j > 2 * lay.world) return;
+  const int d = j >> 1;
+  const int64_t m = (j & 1) ? lay.first[d + 1] - 1 : lay.first[d];
+  const double u = r + ((double)m / (double)m_total);
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (u > cdf[mid]) lo = mid + 1; else hi = mid;
+  }
+  counts[j] = lo;
+}
+
+int launch_dshard_scan(mclhip_ctx* c, const double* d_all_chunks, const ShardLayout& lay, void* d_rec_out, int cap) {
+  hipLaunchKernelGGL(shard_totals_kernel, dim3(1), dim3(64), 0, c->stream, d_all_chunks, lay, c->scal);
+  MCL_TRY_W(launch_shard_scan(c, 0.0, 0.0, c->first_index, c->scal + 5));
+  hipLaunchKernelGGL(export_records_kernel, dim3(1), dim3(256), 0, c->stream, (const unsigned long long*)c->kscan,
+                     c->fscan, (const IrrRecord*)c->irr, c->M, cap, (unsigned long long*)d_rec_out);
+  MCL_HIP(c, hipGetLastError());
+  return MCLHIP_OK;
+}
+
+int launch_dshard_finalize(mclhip_ctx* c, const void* d_all_rec, const ShardLayout& lay, int cap, double r,
+                           int64_t* d_counts) {
+  unsigned long long* meta = reinterpret_cast<unsigned long long*>(c->small_i);   // [4] of the 1024-entry staging
+  hipLaunchKernelGGL(merge_records_kernel, dim3(1), dim3(256), 0, c->stream, (const unsigned long long*)d_all_rec,
+                     lay.world, lay.rank, cap, (IrrRecord*)c->g_records, meta);
+  MCL_TRY_W(launch_shard_finalize(c, c->g_records, 0, c->g_bases, 0, 0, meta));
+  hipLaunchKernelGGL(count_edges_kernel, dim3(1), dim3(256), 0, c->stream, c->cdf_exact, c->M, r, lay, c->m_total,
+                     meta, d_counts);
   MCL_HIP(c, hipGetLastError());
   return MCLHIP_OK;
 }

@@ -157,7 +157,10 @@ def sequential_sum(values):
 class ShardedFilter:
     """Drives one MCL update per call over `world` ranks."""
 
-    def __init__(self, ctx_or_backend, dist, rank, world, m_local, weight_mode=_lib.W_LOG, force_collectives=False):
+    RECORD_CAP = 256     # irregular records per rank that fit the fixed-size exchange of the device-driven step
+
+    def __init__(self, ctx_or_backend, dist, rank, world, m_local, weight_mode=_lib.W_LOG, force_collectives=False,
+                 device_path=None):
         self.b = HipShardBackend(ctx_or_backend) if isinstance(ctx_or_backend, _lib.Context) else ctx_or_backend
         self.dist, self.rank, self.world, self.mode = dist, rank, world, weight_mode
         self.m_local = int(m_local)
@@ -174,16 +177,142 @@ class ShardedFilter:
             self.m_total = self.firsts[-1]
             self.b.set_range(self.firsts[rank], self.m_total)
             self.chunk_cap = 8 * max((n + CHUNK - 1) // CHUNK for n in self.sizes)   # bytes of the longest chunk-sum list
+            if device_path is None:
+                device_path = (self.coll.backend == "nccl" and weight_mode == _lib.W_LOG and
+                               isinstance(self.b, HipShardBackend))
+            self.device_path = bool(device_path)
+            if self.device_path:
+                self._device_setup(self.coll.torch, self.coll.dev)
         else:
             self.sizes, self.firsts, self.m_total = [self.m_local], [0, self.m_local], self.m_local
+            self.device_path = False
+
+    @classmethod
+    def for_layout(cls, ctx, rank, sizes, weight_mode=_lib.W_LOG):
+        """A device-path filter for rank `rank` of a known layout, without a process group: whoever
+        drives its _device_step generator supplies the exchanges (used to run several ranks inside
+        one process)."""
+        import torch
+        self = cls.__new__(cls)
+        self.b = HipShardBackend(ctx)
+        self.dist, self.rank, self.world, self.mode = None, rank, len(sizes), weight_mode
+        self.sizes = [int(n) for n in sizes]
+        self.m_local = self.sizes[rank]
+        self.firsts = [int(x) for x in np.concatenate([[0], np.cumsum(self.sizes)])]
+        self.m_total = self.firsts[-1]
+        self.last_idx, self.collective, self.device_path, self.coll = None, True, True, None
+        self.b.set_range(self.firsts[rank], self.m_total)
+        self.chunk_cap = 8 * max((n + CHUNK - 1) // CHUNK for n in self.sizes)
+        self._device_setup(torch, torch.device("cuda", torch.cuda.current_device()))
+        return self
+
+    # -- device-driven step: collectives on device tensors, one host read per step ------------
+    def _device_setup(self, torch, dev):
+        W = self.world
+        cmax = self.chunk_cap // 8
+        rb = 2 + 3 * self.RECORD_CAP          # 64-bit words per rank: header + records of 24 bytes
+        self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self.t_max = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.t_chunks = torch.zeros(cmax, dtype=torch.float64, device=dev)
+        self.t_all_chunks = torch.zeros(W * cmax, dtype=torch.float64, device=dev)
+        self.t_rec = torch.zeros(rb, dtype=torch.int64, device=dev)
+        self.t_all_rec = torch.zeros(W * rb, dtype=torch.int64, device=dev)
+        self.t_counts = torch.zeros(2 * W + 1, dtype=torch.int64, device=dev)
+        self._torch = torch
+        self._keep = None
+        if self.stream is not None:
+            self.b.ctx.set_stream(self.stream.cuda_stream)
+
+    def _device_step(self, v, omega, dt, alpha, z_meas, r, seed, noise_ints):
+        """Generator: enqueues this rank's work and yields the exchanges it needs, in order --
+        ("all_reduce_max", t), ("all_gather", out, inp), ("all_reduce_sum_read", t) -> numpy,
+        ("all_to_all", send, send_counts, recv_counts) -> recv.  Returns False if a rank had more
+        irregular records than the fixed exchange holds (the caller then finishes on the host path)."""
+        ctx, rank, world, cap = self.b.ctx, self.rank, self.world, self.RECORD_CAP
+        ctx.dshard_sample_max(v, omega, dt, alpha, z_meas, noise_ints, seed, self.mode, self.t_max.data_ptr())
+        yield ("all_reduce_max", self.t_max)
+        ctx.dshard_weights(self.t_max.data_ptr(), self.t_chunks.data_ptr())
+        yield ("all_gather", self.t_all_chunks, self.t_chunks)
+        ctx.dshard_scan(self.t_all_chunks.data_ptr(), self.firsts, rank, self.t_rec.data_ptr(), cap)
+        yield ("all_gather", self.t_all_rec, self.t_rec)
+        ctx.dshard_finalize(self.t_all_rec.data_ptr(), self.firsts, rank, cap, r, self.t_counts.data_ptr())
+        counts = yield ("all_reduce_sum_read", self.t_counts)
+        if counts[-1] > 0:
+            return False
+        gidx = np.minimum(counts[:-1], self.m_total - 1)
+        lo, hi, send_counts, recv_counts, glo = self._plan(gidx)
+        send = self._torch.empty((max(sum(send_counts), 1), 5), dtype=self._torch.float64, device=self.t_max.device)
+        if sum(send_counts):
+            ctx.dshard_pack(lo, hi, send.data_ptr())
+        recv = yield ("all_to_all", send, send_counts, recv_counts)
+        ctx.dshard_unpack_resample(recv.data_ptr(), int(sum(recv_counts)), r, int(glo[rank]))
+        self._keep = (send, recv)       # alive until the next step has been enqueued behind them
+        return True
+
+    def _plan(self, gidx):
+        """Row slices to send to / receive from every rank, from the global source indices of every
+        rank's first and last position."""
+        rank, world = self.rank, self.world
+        glo, ghi = gidx[0::2], gidx[1::2]
+        my_lo, my_hi = self.firsts[rank], self.firsts[rank + 1] - 1
+        lo, hi, send_counts = [], [], []
+        for d in range(world):          # what this rank sends to d
+            a, z = max(int(glo[d]), my_lo), min(int(ghi[d]), my_hi)
+            n = max(0, z - a + 1)
+            send_counts.append(n)
+            lo.append(a - my_lo if n else 0)
+            hi.append(z - my_lo + 1 if n else 0)
+        recv_counts = []
+        for s in range(world):          # what this rank receives from s
+            a, z = max(int(glo[rank]), self.firsts[s]), min(int(ghi[rank]), self.firsts[s + 1] - 1)
+            recv_counts.append(max(0, z - a + 1))
+        return lo, hi, send_counts, recv_counts, glo
+
+    def _drive(self, gen):
+        """Serve the exchanges of one rank's _device_step with torch.distributed on the step's stream."""
+        torch, dist = self._torch, self.dist
+        with torch.cuda.stream(self.stream):
+            try:
+                req = next(gen)
+                while True:
+                    op = req[0]
+                    val = None
+                    if op == "all_reduce_max":
+                        dist.all_reduce(req[1], op=dist.ReduceOp.MAX)
+                    elif op == "all_gather":
+                        dist.all_gather_into_tensor(req[1], req[2])
+                    elif op == "all_reduce_sum_read":
+                        dist.all_reduce(req[1], op=dist.ReduceOp.SUM)
+                        val = req[1].cpu().numpy()
+                    elif op == "all_to_all":
+                        send, sc, rc = req[1], req[2], req[3]
+                        val = torch.empty((max(int(sum(rc)), 1), 5), dtype=torch.float64, device=send.device)
+                        dist.all_to_all_single(val[:int(sum(rc))], send[:int(sum(sc))], [int(c) for c in rc],
+                                               [int(c) for c in sc])
+                    req = gen.send(val)
+            except StopIteration as done:
+                return done.value
 
     def step(self, v, omega, dt, alpha, z_meas, r, seed=0, noise_ints=None, want_idx=False):
         """r = (uniform draw) / M_total, identical on every rank."""
         if not self.collective:
             self.b.step_single(v, omega, dt, alpha, z_meas, r, noise_ints, seed, self.mode, wait=want_idx)
             return
+        if self.device_path:
+            ok = self._drive(self._device_step(v, omega, dt, alpha, z_meas, r, seed, noise_ints))
+            if ok:
+                self.total = None
+                self.last_idx = self.b.ctx.get_indices() if want_idx else None
+                return
+            self.fallbacks = getattr(self, "fallbacks", 0) + 1
+            self._finish_on_host(r, want_idx)    # too many irregular records for the fixed exchange
+            return
+        self.b.sample(v, omega, dt, alpha, z_meas, noise_ints, seed, self.mode)
+        self._finish_on_host(r, want_idx)
+
+    def _finish_on_host(self, r, want_idx):
+        """Everything after the sampling, with the host combining the ranks' small results."""
         b, co, rank, world = self.b, self.coll, self.rank, self.world
-        b.sample(v, omega, dt, alpha, z_meas, noise_ints, seed, self.mode)
         gmax = co.allreduce_max(b.max_logw()) if self.mode == _lib.W_LOG else 0.0
         # global sum in numpy's order: chunk sums of all ranks, added left to right
         chunks = b.weights(self.mode, gmax)
@@ -218,19 +347,7 @@ class ShardedFilter:
             m_edge += [self.firsts[d], self.firsts[d + 1] - 1]
         U = np.array([r + (m / M) for m in m_edge], np.float64)   # mc_localization.py:254
         gidx = np.minimum(co.allreduce_sum_i64(b.count_below(U)), M - 1)
-        glo, ghi = gidx[0::2], gidx[1::2]
-        my_lo, my_hi = self.firsts[rank], self.firsts[rank + 1] - 1
-        lo, hi, send_counts = [], [], []
-        for d in range(world):          # what this rank sends to d
-            a, z = max(int(glo[d]), my_lo), min(int(ghi[d]), my_hi)
-            n = max(0, z - a + 1)
-            send_counts.append(n)
-            lo.append(a - my_lo if n else 0)
-            hi.append(z - my_lo + 1 if n else 0)
-        recv_counts = []
-        for s in range(world):          # what this rank receives from s
-            a, z = max(int(glo[rank]), self.firsts[s]), min(int(ghi[rank]), self.firsts[s + 1] - 1)
-            recv_counts.append(max(0, z - a + 1))
+        lo, hi, send_counts, recv_counts, glo = self._plan(gidx)
         send = co.rows(sum(send_counts))
         if sum(send_counts):
             b.pack(lo, hi, send)

@@ -65,20 +65,22 @@ def test_two_ranks_equal_one_context(sizes, dtype, mode, devnoise):
     assert np.array_equal(np.concatenate([x["w"] for x in res]), wr)
 
 
-def _rccl_rank_fn(rank, world, dist, M, z_meas):
+def _rccl_rank_fn(rank, world, dist, M, z_meas, device_path, record_cap=256):
     from slam_amd import _lib
     from slam_amd.sharded import ShardedFilter
+    ShardedFilter.RECORD_CAP = record_cap
     X, noise, r = _inputs(M)
     ctx = _setup(_lib.F64)
     ctx.set_particles(X)
-    f = ShardedFilter(ctx, dist, 0, 1, M, weight_mode=_lib.W_LOG, force_collectives=True)
-    assert f.coll.backend == "nccl" and f.coll.dev.type == "cuda"
+    f = ShardedFilter(ctx, dist, 0, 1, M, weight_mode=_lib.W_LOG, force_collectives=True, device_path=device_path)
+    assert f.coll.backend == "nccl" and f.coll.dev.type == "cuda" and f.device_path == device_path
     f.step(1.5, 0.0, 0.1, ALPHA, z_meas, r, seed=99, noise_ints=noise, want_idx=True)
     Xo, wo, _ = ctx.get_particles()
-    return {"idx": f.last_idx, "X": Xo, "w": wo, "total": f.total}
+    return {"idx": f.last_idx, "X": Xo, "w": wo, "total": f.total, "fallbacks": getattr(f, "fallbacks", 0)}
 
 
-def test_rccl_path_with_device_tensors_on_one_rank():
+@pytest.mark.parametrize("device_path", [False, True])
+def test_rccl_path_with_device_tensors_on_one_rank(device_path):
     """The cross-rank path under the "nccl" backend (RCCL) with a group of one, in a fresh process
     that brings torch's HIP runtime up first (as bench.py does): the collectives run on GPU
     tensors, and packed rows travel between torch's device memory and the library's through raw
@@ -93,7 +95,121 @@ def test_rccl_path_with_device_tensors_on_one_rank():
     total = ref.normalise(_lib.W_LOG)
     idx = ref.resample(r, _lib.RESAMPLE_PARALLEL)
     Xr, wr, _ = ref.get_particles()
-    res = run_ranks(_rccl_rank_fn, 1, M, z_meas, backend="nccl")[0]
-    assert res["total"] == total
+    res = run_ranks(_rccl_rank_fn, 1, M, z_meas, device_path, backend="nccl")[0]
+    assert device_path or res["total"] == total
+    assert np.array_equal(res["idx"], idx)
+    assert np.array_equal(res["X"], Xr) and np.array_equal(res["w"], wr)
+
+
+def _lockstep_fn(rank, world, dist, sizes, z_meas, record_cap):
+    """Several ranks of the device-driven step inside ONE process (one context per rank on the same
+    GPU); the exchanges between them are done here with plain tensor operations, so that the
+    device kernels that combine the ranks' data see real multi-rank inputs."""
+    import torch
+    from slam_amd import _lib
+    from slam_amd.sharded import ShardedFilter
+    torch.cuda.set_device(0)
+    M = sum(sizes)
+    X, noise, r = _inputs(M)
+    W = len(sizes)
+    ShardedFilter.RECORD_CAP = record_cap
+    filt, gens, req = [], [], []
+    for k in range(W):
+        first = sum(sizes[:k])
+        ctx = _setup(_lib.F32)
+        ctx.set_particles(X[first:first + sizes[k]])
+        f = ShardedFilter.for_layout(ctx, k, sizes)
+        filt.append(f)
+        gens.append(f._device_step(1.5, 0.0, 0.1, ALPHA, z_meas, r, 99, noise[first:first + sizes[k]]))
+
+    def settle():
+        for f in filt:
+            f.b.ctx.sync()
+        torch.cuda.synchronize()
+
+    req = [next(g) for g in gens]
+    done = [None] * W
+    while any(d is None for d in done):
+        settle()
+        op = req[0][0]
+        vals = [None] * W
+        if op == "all_reduce_max":
+            m = torch.stack([q[1] for q in req]).max(0).values
+            for q in req:
+                q[1].copy_(m)
+        elif op == "all_gather":
+            cat = torch.cat([q[2] for q in req])
+            for q in req:
+                q[1].copy_(cat)
+        elif op == "all_reduce_sum_read":
+            tot = torch.stack([q[1] for q in req]).sum(0)
+            vals = [tot.cpu().numpy() for _ in req]
+        elif op == "all_to_all":
+            offs = [np.concatenate([[0], np.cumsum(q[2])]).astype(int) for q in req]
+            for d in range(W):
+                parts = [req[s][1][offs[s][d]:offs[s][d + 1]] for s in range(W)]
+                assert [len(p) for p in parts] == [int(c) for c in req[d][3]]
+                rows = torch.cat(parts) if sum(len(p) for p in parts) else torch.empty((1, 5), dtype=torch.float64, device="cuda")
+                vals[d] = rows.contiguous()
+        settle()
+        for k in range(W):
+            try:
+                req[k] = gens[k].send(vals[k])
+            except StopIteration as e:
+                done[k] = e.value
+    settle()
+    out = []
+    for k, f in enumerate(filt):
+        Xo, wo, _ = f.b.ctx.get_particles()
+        out.append({"ok": done[k], "idx": f.b.ctx.get_indices() if done[k] else None, "X": Xo, "w": wo})
+    return out
+
+
+@pytest.mark.parametrize("sizes", [(16384, 8192), (8192, 8192, 11000), (8192,) * 8])
+def test_device_driven_step_of_several_ranks_equals_one_context(sizes):
+    """The device-side combination of several ranks' chunk sums, record lists and boundary counts,
+    fed with real multi-rank data (ranks run in lockstep inside one process): bit-equal to the
+    fused single-context update."""
+    from slam_amd import _lib
+    M = sum(sizes)
+    X, noise, r = _inputs(M)
+    ref = _setup(_lib.F32)
+    z_meas = ref.raycast(np.array([3.0, 4.5, 0.0]), want_hits=False)[0][0]
+    ref.set_particles(X)
+    ref.sample(1.5, 0.0, 0.1, ALPHA, z_meas, noise, seed=99)
+    ref.normalise(_lib.W_LOG)
+    idx = ref.resample(r, _lib.RESAMPLE_PARALLEL)
+    Xr, wr, _ = ref.get_particles()
+    res = run_ranks(_lockstep_fn, 1, sizes, z_meas, 256, backend="nccl")[0]
+    assert all(x["ok"] for x in res)
+    assert np.array_equal(np.concatenate([x["idx"] for x in res]), idx)
+    assert np.array_equal(np.concatenate([x["X"] for x in res]), Xr)
+    assert np.array_equal(np.concatenate([x["w"] for x in res]), wr)
+
+
+def test_device_driven_step_reports_record_overflow():
+    from slam_amd import _lib
+    sizes = (8192, 8192)
+    ref = _setup(_lib.F32)
+    z_meas = ref.raycast(np.array([3.0, 4.5, 0.0]), want_hits=False)[0][0]
+    res = run_ranks(_lockstep_fn, 1, sizes, z_meas, 1, backend="nccl")[0]
+    assert all(x["ok"] is False for x in res)
+
+
+def test_device_driven_step_falls_back_to_the_host_path_on_overflow():
+    """With room for a single record per rank the fixed exchange overflows (24576 weights cross a few
+    binades): the step must finish on the host path with the same result."""
+    from slam_amd import _lib
+    M = 24576
+    X, noise, r = _inputs(M)
+    ref = _setup(_lib.F64)
+    z_meas = ref.raycast(np.array([3.0, 4.5, 0.0]), want_hits=False)[0][0]
+    ref.set_particles(X)
+    ref.sample(1.5, 0.0, 0.1, ALPHA, z_meas, noise, seed=99)
+    total = ref.normalise(_lib.W_LOG)
+    idx = ref.resample(r, _lib.RESAMPLE_PARALLEL)
+    Xr, wr, _ = ref.get_particles()
+    res = run_ranks(_rccl_rank_fn, 1, M, z_meas, True, 1, backend="nccl")[0]
+    assert res["fallbacks"] == 1 and res["total"] == total
     assert np.array_equal(res["idx"], idx)
     assert np.array_equal(res["X"], Xr) and np.array_equal(res["w"], wr)
