@@ -326,6 +326,29 @@ int mclhip_fs_step(mclhip_ctx* ctx, double v, double omega, double dt, const dou
 int mclhip_fs_get_state(mclhip_ctx* ctx, double* pose, double* w, int32_t* nfeat, int32_t* new_id, double* f_m,
                         double* f_cov, int32_t* f_i, double* f_w, int32_t* f_id);
 
+/* One FastSLAM filter over several GPUs (no counterpart in the reference, which is
+ * single-process): contiguous particle ranges per rank (mclhip_shard_set), the
+ * weight sum and the running sums in the reference's strictly sequential order
+ * through the mclhip_shard_scan / _finalize exchange, poses and weights in the
+ * 5-double rows of mclhip_shard_pack, feature slots in rows of
+ * mclhip_fs_row_words() 64-bit words. */
+
+/* The per-particle part of fast_slam1.py:246-404 on this rank's particles (device
+ * generators are keyed by the global particle index); leaves the raw weights. */
+int mclhip_fs_shard_kernel(mclhip_ctx* ctx, double v, double omega, double dt, const double alpha[6],
+                           const double* truth_r, const double* truth_phi, const uint8_t* truth_valid, int L,
+                           const int16_t* ints, const double* normals, uint64_t seed);
+/* Last running sum of this rank after mclhip_shard_finalize (the last rank's value
+ * is the sum of all weights, added one by one as fast_slam1.py:411-413 does). */
+int mclhip_fs_shard_last_sum(mclhip_ctx* ctx, double* last_out);
+/* 64-bit words per particle in a feature row: 2 + 9 * capacity. */
+int64_t mclhip_fs_row_words(mclhip_ctx* ctx);
+/* Feature rows of the local particles [lo[k], hi[k]) -> rows (host or device memory). */
+int mclhip_fs_shard_pack(mclhip_ctx* ctx, const int64_t* lo, const int64_t* hi, int nslices, void* rows);
+/* After mclhip_shard_unpack_resample: every local particle takes the feature slots
+ * of its ancestor from the L received rows (global index of row 0 = row0_global). */
+int mclhip_fs_shard_unpack(mclhip_ctx* ctx, const void* rows, int64_t L, int64_t row0_global);
+
 /* Measurement ------------------------------------------------------------ */
 
 /* Per-kernel timing with HIP events on the context's own stream.

@@ -90,6 +90,12 @@ PROTOTYPES = {
     "mclhip_fs_step": (C.c_int, [_ctx_p, C.c_double, C.c_double, C.c_double, _dbl_p, _dbl_p, _dbl_p, _u8_p, C.c_int,
                                  _i16_p, _dbl_p, C.c_uint64, C.c_double, _i64_p]),
     "mclhip_fs_get_state": (C.c_int, [_ctx_p, _dbl_p, _dbl_p, _i32_p, _i32_p, _dbl_p, _dbl_p, _i32_p, _dbl_p, _i32_p]),
+    "mclhip_fs_shard_kernel": (C.c_int, [_ctx_p, C.c_double, C.c_double, C.c_double, _dbl_p, _dbl_p, _dbl_p, _u8_p,
+                                         C.c_int, _i16_p, _dbl_p, C.c_uint64]),
+    "mclhip_fs_shard_last_sum": (C.c_int, [_ctx_p, _dbl_p]),
+    "mclhip_fs_row_words": (C.c_int64, [_ctx_p]),
+    "mclhip_fs_shard_pack": (C.c_int, [_ctx_p, _i64_p, _i64_p, C.c_int, C.c_void_p]),
+    "mclhip_fs_shard_unpack": (C.c_int, [_ctx_p, C.c_void_p, C.c_int64, C.c_int64]),
     "mclhip_timing_enable": (C.c_int, [_ctx_p, C.c_int]),
     "mclhip_timing_get": (C.c_int, [_ctx_p, C.c_int, _i64_p, _dbl_p]),
 }
@@ -480,6 +486,39 @@ class Context:
                                          _p(tp, _dbl_p), _p(tv, _u8_p), L, _p(ints, _i16_p), _p(normals, _dbl_p),
                                          int(seed), float(r), _p(idx, _i64_p)), "mclhip_fs_step")
         return idx
+
+    def fs_shard_kernel(self, v, omega, dt, alpha, truth_r, truth_phi, truth_valid, ints, normals, seed=0):
+        al = _f64(alpha, (6,))
+        tr_, tp = _f64(truth_r), _f64(truth_phi)
+        tv = np.ascontiguousarray(truth_valid, dtype=np.uint8)
+        nv = int(np.count_nonzero(tv))
+        if ints is not None:
+            ints = np.ascontiguousarray(ints, dtype=np.int16)
+            if ints.shape != (self.fs_M, 3, 12):
+                raise ValueError("ints must have shape (M, 3, 12)")
+        if normals is not None:
+            normals = _f64(normals, (self.fs_M, 2 * nv))
+        self._ck(self.lib.mclhip_fs_shard_kernel(self.h, float(v), float(omega), float(dt), _p(al, _dbl_p),
+                                                 _p(tr_, _dbl_p), _p(tp, _dbl_p), _p(tv, _u8_p), len(tr_),
+                                                 _p(ints, _i16_p), _p(normals, _dbl_p), int(seed)), "mclhip_fs_shard_kernel")
+
+    def fs_shard_last_sum(self):
+        v = C.c_double(0.0)
+        self._ck(self.lib.mclhip_fs_shard_last_sum(self.h, C.byref(v)), "mclhip_fs_shard_last_sum")
+        return v.value
+
+    def fs_row_words(self):
+        return int(self.lib.mclhip_fs_row_words(self.h))
+
+    def fs_shard_pack(self, lo, hi, rows_ptr):
+        lo = np.ascontiguousarray(lo, np.int64)
+        hi = np.ascontiguousarray(hi, np.int64)
+        self._ck(self.lib.mclhip_fs_shard_pack(self.h, _p(lo, _i64_p), _p(hi, _i64_p), len(lo), C.c_void_p(rows_ptr)),
+                 "mclhip_fs_shard_pack")
+
+    def fs_shard_unpack(self, rows_ptr, L, row0_global):
+        self._ck(self.lib.mclhip_fs_shard_unpack(self.h, C.c_void_p(rows_ptr), int(L), int(row0_global)),
+                 "mclhip_fs_shard_unpack")
 
     def fs_get_state(self):
         M, F = self.fs_M, self.fs_cap

@@ -32,6 +32,7 @@ struct FsParams {
   const double* normals;    // [M][n_norm] or null
   int n_norm;
   uint64_t seed;
+  int64_t index0;           // global index of local particle 0 (keys the device generators)
   const double* tr; const double* tphi; const uint8_t* tvalid;   // [L] noise-free measurements
   double *x, *y, *th, *wout;
   int32_t *nfeat, *new_id, *fi, *fid;
@@ -107,7 +108,8 @@ __global__ __launch_bounds__(128) void fs_step_kernel(FsParams P) {
   } else {
 #pragma unroll
     for (int b = 0; b < 9; ++b) {
-      uint32_t ctr[4] = {(uint32_t)p, (uint32_t)((uint64_t)p >> 32), (uint32_t)b, 0x4d4fu};
+      const uint64_t gp = (uint64_t)(P.index0 + p);
+      uint32_t ctr[4] = {(uint32_t)gp, (uint32_t)(gp >> 32), (uint32_t)b, 0x4d4fu};
       philox4x32(ctr, (uint32_t)P.seed, (uint32_t)(P.seed >> 32));
 #pragma unroll
       for (int j = 0; j < 4; ++j) k[b * 4 + j] = (int)(((uint64_t)ctr[j] * 2000ull) >> 32) - 1000;   // randint(-1000, 1000)
@@ -161,8 +163,8 @@ __global__ __launch_bounds__(128) void fs_step_kernel(FsParams P) {
         n_r = P.normals[p * P.n_norm + used];
         n_phi = P.normals[p * P.n_norm + used + 1];
       } else {
-        n_r = device_normal((uint64_t)p, (uint32_t)used, P.seed);
-        n_phi = device_normal((uint64_t)p, (uint32_t)used + 1u, P.seed);
+        n_r = device_normal((uint64_t)(P.index0 + p), (uint32_t)used, P.seed);
+        n_phi = device_normal((uint64_t)(P.index0 + p), (uint32_t)used + 1u, P.seed);
       }
       used += 2;
       const double zr = P.tr[l] + n_r * P.std_r;   // :145-152
@@ -297,6 +299,49 @@ __global__ void fs_divide_kernel(double* __restrict__ w, int64_t n, const double
   if (i < n) w[i] = w[i] / scal[3];   // :418
 }
 
+// Feature rows for the exchange between ranks: per particle 2 + 9 F 64-bit words --
+// [nfeat, new_id, then per slot: m0 m1 c00 c01 c10 c11 w (doubles), i, id].  Block row y = 0 handles the
+// two counters, y = 1 + slot the slots.
+__global__ void fs_pack_rows_kernel(int64_t lo, int64_t n, int64_t M, int F, const int32_t* __restrict__ nfeat,
+                                    const int32_t* __restrict__ newid, const double* const* fd, const int32_t* const* fi,
+                                    unsigned long long* __restrict__ out) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int64_t p = lo + j;
+  unsigned long long* row = out + j * (2 + (int64_t)9 * F);
+  const int y = blockIdx.y;
+  if (y == 0) { row[0] = (unsigned long long)(long long)nfeat[p]; row[1] = (unsigned long long)(long long)newid[p]; return; }
+  const int slot = y - 1;
+  if (slot >= nfeat[p]) return;
+  unsigned long long* dst = row + 2 + (int64_t)9 * slot;
+  const int64_t a = (int64_t)slot * M + p;
+#pragma unroll
+  for (int f = 0; f < 7; ++f) dst[f] = (unsigned long long)__double_as_longlong(fd[f][a]);
+  dst[7] = (unsigned long long)(long long)fi[0][a];
+  dst[8] = (unsigned long long)(long long)fi[1][a];
+}
+
+__global__ void fs_unpack_rows_kernel(const int64_t* __restrict__ idx, int64_t row0_global, int64_t L, int64_t M, int F,
+                                      const unsigned long long* __restrict__ rows, int32_t* __restrict__ nfeat,
+                                      int32_t* __restrict__ newid, double* const* fd, int32_t* const* fi) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= M) return;
+  int64_t rr = idx[p] - row0_global;
+  rr = rr < 0 ? 0 : (rr > L - 1 ? L - 1 : rr);
+  const unsigned long long* row = rows + rr * (2 + (int64_t)9 * F);
+  const int n = (int)(long long)row[0];
+  const int y = blockIdx.y;
+  if (y == 0) { nfeat[p] = n; newid[p] = (int)(long long)row[1]; return; }
+  const int slot = y - 1;
+  if (slot >= n) return;
+  const unsigned long long* src = row + 2 + (int64_t)9 * slot;
+  const int64_t b = (int64_t)slot * M + p;
+#pragma unroll
+  for (int f = 0; f < 7; ++f) fd[f][b] = __longlong_as_double((long long)src[f]);
+  fi[0][b] = (int)(long long)src[7];
+  fi[1][b] = (int)(long long)src[8];
+}
+
 }  // namespace mcl
 
 using namespace mcl;
@@ -316,7 +361,8 @@ struct FsState {
   int32_t* overflow = nullptr;
   double* d_truth = nullptr; uint8_t* d_valid = nullptr; int truth_cap = 0;
   int16_t* d_ints = nullptr; double* d_normals = nullptr; int64_t normals_cap = 0;
-  void** d_ptrs = nullptr;   // pointer tables for the gather kernel
+  void** d_ptrs = nullptr;   // pointer tables: [0..6] doubles of buffer 0, [7..13] of buffer 1, [14..15] / [16..17] ints
+  unsigned long long* stage = nullptr; int64_t stage_words = 0;   // feature rows on their way to / from another rank
   double std_r = 0.5, std_phi = 3 * M_PI / 180.0, r_max = 10.0, p0 = 0.01, thres_sig = 2.0;
 };
 
@@ -329,7 +375,7 @@ static void fs_free(FsState* s) {
     if (s->newid[b]) (void)hipFree(s->newid[b]);
   }
   for (auto& q : s->scratch) if (q) (void)hipFree(q);
-  void* rest[] = {s->upd, s->overflow, s->d_truth, s->d_valid, s->d_ints, s->d_normals, s->d_ptrs};
+  void* rest[] = {s->upd, s->overflow, s->d_truth, s->d_valid, s->d_ints, s->d_normals, s->d_ptrs, s->stage};
   for (void* q : rest) if (q) (void)hipFree(q);
   delete s;
 }
@@ -339,8 +385,94 @@ void mcl::fs_release(mclhip_ctx* c) {
   c->fs = nullptr;
 }
 
+static int fs_stage(mclhip_ctx* c, FsState* s, int64_t words) {
+  if (words <= s->stage_words) return MCLHIP_OK;
+  if (s->stage) { (void)hipStreamSynchronize(c->stream); (void)hipFree(s->stage); s->stage = nullptr; }
+  const int64_t cap = words + words / 4;
+  MCL_HIP(c, hipMalloc((void**)&s->stage, (size_t)cap * 8));
+  s->stage_words = cap;
+  return MCLHIP_OK;
+}
+
+static int fs_upload_tables(mclhip_ctx* c, FsState* s) {
+  void* tab[18];
+  for (int f = 0; f < 7; ++f) { tab[f] = s->fd[0][f]; tab[7 + f] = s->fd[1][f]; }
+  for (int f = 0; f < 2; ++f) { tab[14 + f] = s->fint[0][f]; tab[16 + f] = s->fint[1][f]; }
+  MCL_HIP(c, hipMemcpyAsync(s->d_ptrs, tab, sizeof(tab), hipMemcpyHostToDevice, c->stream));
+  MCL_HIP(c, hipStreamSynchronize(c->stream));   // tab is a stack array
+  return MCLHIP_OK;
+}
+
 #define F_TRY(expr) do { int rc__ = (expr); if (rc__ != MCLHIP_OK) return rc__; } while (0)
 #define F_HIP(expr) MCL_HIP(c, expr)
+
+// uploads the step's inputs and enqueues the per-particle kernel (pose sample .. weight / decay pass)
+static int fs_enqueue_kernel(mclhip_ctx* c, double v, double omega, double dt, const double alpha[6], const double* truth_r,
+                             const double* truth_phi, const uint8_t* truth_valid, int L, const int16_t* ints,
+                             const double* normals, uint64_t seed) {
+  if (!c) return MCLHIP_E_ARG;
+  F_HIP(hipSetDevice(c->device));
+  if (!c->fs) return fail(c, MCLHIP_E_STATE, "call mclhip_fs_init first");
+  if (!alpha || (L > 0 && (!truth_r || !truth_phi || !truth_valid)) || L < 0) return fail(c, MCLHIP_E_ARG, "alpha / truth arrays NULL");
+  FsState* s = (FsState*)c->fs;
+  const int64_t M = s->M;
+  int n_valid = 0;
+  for (int l = 0; l < L; ++l) n_valid += truth_valid[l] ? 1 : 0;
+  if (L > s->truth_cap) {
+    if (s->d_truth) (void)hipFree(s->d_truth);
+    if (s->d_valid) (void)hipFree(s->d_valid);
+    F_HIP(hipMalloc((void**)&s->d_truth, (size_t)2 * L * sizeof(double)));
+    F_HIP(hipMalloc((void**)&s->d_valid, (size_t)L));
+    s->truth_cap = L;
+  }
+  if (L > 0) {
+    F_HIP(hipMemcpyAsync(s->d_truth, truth_r, L * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    F_HIP(hipMemcpyAsync(s->d_truth + L, truth_phi, L * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    F_HIP(hipMemcpyAsync(s->d_valid, truth_valid, L, hipMemcpyHostToDevice, c->stream));
+  }
+  if (ints) {
+    if (!s->d_ints) F_HIP(hipMalloc((void**)&s->d_ints, (size_t)M * 36 * sizeof(int16_t)));
+    F_HIP(hipMemcpyAsync(s->d_ints, ints, (size_t)M * 36 * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
+  }
+  if (normals && n_valid > 0) {
+    const int64_t need = M * 2 * n_valid;
+    if (need > s->normals_cap) {
+      if (s->d_normals) (void)hipFree(s->d_normals);
+      F_HIP(hipMalloc((void**)&s->d_normals, (size_t)need * sizeof(double)));
+      s->normals_cap = need;
+    }
+    F_HIP(hipMemcpyAsync(s->d_normals, normals, (size_t)need * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  }
+  const int a = s->cur;
+  FsParams P;
+  P.M = M; P.F = s->F; P.L = L;
+  P.v = v; P.w = omega; P.dt = dt;
+  P.c1 = (alpha[0] * std::fabs(v) + alpha[1] * std::fabs(omega)) / 6.0;   // b/6.0 (:164, :181-183)
+  P.c2 = (alpha[2] * std::fabs(v) + alpha[3] * std::fabs(omega)) / 6.0;
+  P.c3 = (alpha[4] * std::fabs(v) + alpha[5] * std::fabs(omega)) / 6.0;
+  P.qt_r = std::pow(s->std_r, 2.0); P.qt_phi = std::pow(s->std_phi, 2.0);   // std_r**2, std_phi**2 (:267-268)
+  P.std_r = s->std_r; P.std_phi = s->std_phi; P.r_max = s->r_max; P.r_max2 = std::pow(s->r_max, 2.0);
+  P.p0 = s->p0; P.gate2 = std::pow(s->thres_sig, 2.0);
+  P.ints = ints ? s->d_ints : nullptr;
+  P.normals = (normals && n_valid > 0) ? s->d_normals : nullptr;
+  P.n_norm = 2 * n_valid;
+  P.seed = seed;
+  P.index0 = c->first_index;
+  P.tr = s->d_truth; P.tphi = s->d_truth ? s->d_truth + L : nullptr; P.tvalid = s->d_valid;
+  P.x = (double*)c->px[c->cur]; P.y = (double*)c->py[c->cur]; P.th = (double*)c->pth[c->cur]; P.wout = c->w[c->cur];
+  P.nfeat = s->nfeat[a]; P.new_id = s->newid[a];
+  P.fm0 = s->fd[a][0]; P.fm1 = s->fd[a][1]; P.c00 = s->fd[a][2]; P.c01 = s->fd[a][3]; P.c10 = s->fd[a][4];
+  P.c11 = s->fd[a][5]; P.fw = s->fd[a][6];
+  P.fi = s->fint[a][0]; P.fid = s->fint[a][1];
+  P.zr = s->scratch[0]; P.zphi = s->scratch[1]; P.h00 = s->scratch[2]; P.h01 = s->scratch[3]; P.h10 = s->scratch[4];
+  P.h11 = s->scratch[5]; P.iq00 = s->scratch[6]; P.iq01 = s->scratch[7]; P.iq10 = s->scratch[8]; P.iq11 = s->scratch[9];
+  P.detq = s->scratch[10];
+  P.upd = s->upd; P.overflow = s->overflow;
+  if (!ints && !normals) { /* device generator for both streams */ }
+  hipLaunchKernelGGL(fs_step_kernel, dim3((unsigned)((M + 127) / 128)), dim3(128), 0, c->stream, P);
+  F_HIP(hipGetLastError());
+  return MCLHIP_OK;
+}
 
 extern "C" {
 
@@ -382,66 +514,10 @@ int mclhip_fs_set_model(mclhip_ctx* c, double std_r, double std_phi, double r_ma
 int mclhip_fs_step(mclhip_ctx* c, double v, double omega, double dt, const double alpha[6], const double* truth_r,
                    const double* truth_phi, const uint8_t* truth_valid, int L, const int16_t* ints,
                    const double* normals, uint64_t seed, double r, int64_t* idx_out) {
-  if (!c) return MCLHIP_E_ARG;
-  F_HIP(hipSetDevice(c->device));
-  if (!c->fs) return fail(c, MCLHIP_E_STATE, "call mclhip_fs_init first");
-  if (!alpha || (L > 0 && (!truth_r || !truth_phi || !truth_valid)) || L < 0) return fail(c, MCLHIP_E_ARG, "alpha / truth arrays NULL");
+  F_TRY(fs_enqueue_kernel(c, v, omega, dt, alpha, truth_r, truth_phi, truth_valid, L, ints, normals, seed));
   FsState* s = (FsState*)c->fs;
   const int64_t M = s->M;
-  int n_valid = 0;
-  for (int l = 0; l < L; ++l) n_valid += truth_valid[l] ? 1 : 0;
-  if (L > s->truth_cap) {
-    if (s->d_truth) (void)hipFree(s->d_truth);
-    if (s->d_valid) (void)hipFree(s->d_valid);
-    F_HIP(hipMalloc((void**)&s->d_truth, (size_t)2 * L * sizeof(double)));
-    F_HIP(hipMalloc((void**)&s->d_valid, (size_t)L));
-    s->truth_cap = L;
-  }
-  if (L > 0) {
-    F_HIP(hipMemcpyAsync(s->d_truth, truth_r, L * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    F_HIP(hipMemcpyAsync(s->d_truth + L, truth_phi, L * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    F_HIP(hipMemcpyAsync(s->d_valid, truth_valid, L, hipMemcpyHostToDevice, c->stream));
-  }
-  if (ints) {
-    if (!s->d_ints) F_HIP(hipMalloc((void**)&s->d_ints, (size_t)M * 36 * sizeof(int16_t)));
-    F_HIP(hipMemcpyAsync(s->d_ints, ints, (size_t)M * 36 * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
-  }
-  if (normals && n_valid > 0) {
-    const int64_t need = M * 2 * n_valid;
-    if (need > s->normals_cap) {
-      if (s->d_normals) (void)hipFree(s->d_normals);
-      F_HIP(hipMalloc((void**)&s->d_normals, (size_t)need * sizeof(double)));
-      s->normals_cap = need;
-    }
-    F_HIP(hipMemcpyAsync(s->d_normals, normals, (size_t)need * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  }
   const int a = s->cur, b = 1 - s->cur;
-  FsParams P;
-  P.M = M; P.F = s->F; P.L = L;
-  P.v = v; P.w = omega; P.dt = dt;
-  P.c1 = (alpha[0] * std::fabs(v) + alpha[1] * std::fabs(omega)) / 6.0;   // b/6.0 (:164, :181-183)
-  P.c2 = (alpha[2] * std::fabs(v) + alpha[3] * std::fabs(omega)) / 6.0;
-  P.c3 = (alpha[4] * std::fabs(v) + alpha[5] * std::fabs(omega)) / 6.0;
-  P.qt_r = std::pow(s->std_r, 2.0); P.qt_phi = std::pow(s->std_phi, 2.0);   // std_r**2, std_phi**2 (:267-268)
-  P.std_r = s->std_r; P.std_phi = s->std_phi; P.r_max = s->r_max; P.r_max2 = std::pow(s->r_max, 2.0);
-  P.p0 = s->p0; P.gate2 = std::pow(s->thres_sig, 2.0);
-  P.ints = ints ? s->d_ints : nullptr;
-  P.normals = (normals && n_valid > 0) ? s->d_normals : nullptr;
-  P.n_norm = 2 * n_valid;
-  P.seed = seed;
-  P.tr = s->d_truth; P.tphi = s->d_truth ? s->d_truth + L : nullptr; P.tvalid = s->d_valid;
-  P.x = (double*)c->px[c->cur]; P.y = (double*)c->py[c->cur]; P.th = (double*)c->pth[c->cur]; P.wout = c->w[c->cur];
-  P.nfeat = s->nfeat[a]; P.new_id = s->newid[a];
-  P.fm0 = s->fd[a][0]; P.fm1 = s->fd[a][1]; P.c00 = s->fd[a][2]; P.c01 = s->fd[a][3]; P.c10 = s->fd[a][4];
-  P.c11 = s->fd[a][5]; P.fw = s->fd[a][6];
-  P.fi = s->fint[a][0]; P.fid = s->fint[a][1];
-  P.zr = s->scratch[0]; P.zphi = s->scratch[1]; P.h00 = s->scratch[2]; P.h01 = s->scratch[3]; P.h10 = s->scratch[4];
-  P.h11 = s->scratch[5]; P.iq00 = s->scratch[6]; P.iq01 = s->scratch[7]; P.iq10 = s->scratch[8]; P.iq11 = s->scratch[9];
-  P.detq = s->scratch[10];
-  P.upd = s->upd; P.overflow = s->overflow;
-  if (!ints && !normals) { /* device generator for both streams */ }
-  hipLaunchKernelGGL(fs_step_kernel, dim3((unsigned)((M + 127) / 128)), dim3(128), 0, c->stream, P);
-  F_HIP(hipGetLastError());
   // normalise by the Python-order sum with its 1e-8 floor, then the guarded low-variance walk (:411-431)
   F_TRY(launch_sequential_total(c));                     // c->cdf_exact[M-1] = sum_w, added one by one
   const unsigned g = (unsigned)((M + 255) / 256);
@@ -500,6 +576,85 @@ int mclhip_fs_get_state(mclhip_ctx* c, double* pose, double* w, int32_t* nfeat, 
   };
   if (f_i) F_TRY(pull_i(0, f_i, 0));
   if (f_id) F_TRY(pull_i(1, f_id, -1));
+  return MCLHIP_OK;
+}
+
+/* ---- one FastSLAM filter over several GPUs: the per-rank halves ---- */
+
+int mclhip_fs_shard_kernel(mclhip_ctx* c, double v, double omega, double dt, const double alpha[6], const double* truth_r,
+                           const double* truth_phi, const uint8_t* truth_valid, int L, const int16_t* ints,
+                           const double* normals, uint64_t seed) {
+  F_TRY(fs_enqueue_kernel(c, v, omega, dt, alpha, truth_r, truth_phi, truth_valid, L, ints, normals, seed));
+  FsState* s = (FsState*)c->fs;
+  int32_t ov = 0;
+  F_HIP(hipMemcpyAsync(&ov, s->overflow, sizeof(ov), hipMemcpyDeviceToHost, c->stream));
+  F_HIP(hipStreamSynchronize(c->stream));
+  if (ov) return fail(c, MCLHIP_E_LIMIT, "a particle ran out of feature slots: raise the capacity given to mclhip_fs_init");
+  return MCLHIP_OK;
+}
+
+int mclhip_fs_shard_last_sum(mclhip_ctx* c, double* last_out) {
+  if (!c || !last_out) return MCLHIP_E_ARG;
+  F_HIP(hipSetDevice(c->device));
+  if (c->M <= 0) return fail(c, MCLHIP_E_STATE, "no particles");
+  F_HIP(hipStreamSynchronize(c->stream));
+  F_HIP(hipMemcpy(last_out, c->cdf_exact + (c->M - 1), sizeof(double), hipMemcpyDeviceToHost));
+  return MCLHIP_OK;
+}
+
+int64_t mclhip_fs_row_words(mclhip_ctx* c) {
+  if (!c || !c->fs) return 0;
+  return 2 + (int64_t)9 * ((FsState*)c->fs)->F;
+}
+
+int mclhip_fs_shard_pack(mclhip_ctx* c, const int64_t* lo, const int64_t* hi, int nslices, void* rows) {
+  if (!c) return MCLHIP_E_ARG;
+  F_HIP(hipSetDevice(c->device));
+  if (!c->fs) return fail(c, MCLHIP_E_STATE, "call mclhip_fs_init first");
+  if (!lo || !hi || nslices <= 0) return fail(c, MCLHIP_E_ARG, "lo/hi NULL or no slices");
+  FsState* s = (FsState*)c->fs;
+  const int64_t words = 2 + (int64_t)9 * s->F;
+  int64_t total = 0;
+  for (int k = 0; k < nslices; ++k) {
+    if (lo[k] < 0 || hi[k] > s->M || hi[k] < lo[k]) return fail(c, MCLHIP_E_ARG, "slice outside the local range");
+    total += hi[k] - lo[k];
+  }
+  if (total == 0) return MCLHIP_OK;
+  if (!rows) return fail(c, MCLHIP_E_ARG, "rows is NULL");
+  F_TRY(fs_stage(c, s, total * words));
+  F_TRY(fs_upload_tables(c, s));
+  int64_t off = 0;
+  for (int k = 0; k < nslices; ++k) {
+    const int64_t n = hi[k] - lo[k];
+    if (n == 0) continue;
+    hipLaunchKernelGGL(fs_pack_rows_kernel, dim3((unsigned)((n + 63) / 64), s->F + 1), dim3(64), 0, c->stream, lo[k], n,
+                       s->M, s->F, s->nfeat[s->cur], s->newid[s->cur], (const double* const*)(s->d_ptrs + 7 * s->cur),
+                       (const int32_t* const*)(s->d_ptrs + 14 + 2 * s->cur), s->stage + off * words);
+    off += n;
+  }
+  F_HIP(hipGetLastError());
+  F_HIP(hipMemcpyAsync(rows, s->stage, (size_t)total * words * 8, hipMemcpyDefault, c->stream));
+  F_HIP(hipStreamSynchronize(c->stream));
+  return MCLHIP_OK;
+}
+
+int mclhip_fs_shard_unpack(mclhip_ctx* c, const void* rows, int64_t L, int64_t row0_global) {
+  if (!c) return MCLHIP_E_ARG;
+  F_HIP(hipSetDevice(c->device));
+  if (!c->fs) return fail(c, MCLHIP_E_STATE, "call mclhip_fs_init first");
+  if (!rows || L <= 0) return fail(c, MCLHIP_E_ARG, "rows NULL or empty");
+  FsState* s = (FsState*)c->fs;
+  const int64_t words = 2 + (int64_t)9 * s->F;
+  F_TRY(fs_stage(c, s, L * words));
+  F_TRY(fs_upload_tables(c, s));
+  F_HIP(hipMemcpyAsync(s->stage, rows, (size_t)L * words * 8, hipMemcpyDefault, c->stream));
+  const int b = 1 - s->cur;
+  hipLaunchKernelGGL(fs_unpack_rows_kernel, dim3((unsigned)((s->M + 63) / 64), s->F + 1), dim3(64), 0, c->stream, c->idx,
+                     row0_global, L, s->M, s->F, (const unsigned long long*)s->stage, s->nfeat[b], s->newid[b],
+                     (double* const*)(s->d_ptrs + 7 * b), (int32_t* const*)(s->d_ptrs + 14 + 2 * b));
+  F_HIP(hipGetLastError());
+  F_HIP(hipStreamSynchronize(c->stream));
+  s->cur = b;
   return MCLHIP_OK;
 }
 

@@ -117,13 +117,13 @@ class _Coll:
         self.dist.all_gather(outs, t)
         return [o.cpu().numpy()[:lens[i]].tobytes() for i, o in enumerate(outs)]
 
-    def rows(self, n):
-        return self.torch.empty((max(n, 1), 5), dtype=self.torch.float64, device=self.dev)
+    def rows(self, n, width=5, dtype=None):
+        return self.torch.empty((max(n, 1), width), dtype=dtype or self.torch.float64, device=self.dev)
 
     def all_to_all_rows(self, send, send_counts, recv_counts):
         """Row slices to every rank (send_counts[d] rows to rank d, in order)."""
         torch, dist = self.torch, self.dist
-        recv = self.rows(int(sum(recv_counts)))
+        recv = self.rows(int(sum(recv_counts)), send.shape[1], send.dtype)
         if self.backend == "nccl":
             dist.all_to_all_single(recv[:int(sum(recv_counts))], send[:int(sum(send_counts))],
                                    [int(c) for c in recv_counts], [int(c) for c in send_counts])
@@ -354,3 +354,80 @@ class ShardedFilter:
         recv = co.all_to_all_rows(send, send_counts, recv_counts)
         L = int(sum(recv_counts))
         self.last_idx = b.unpack_resample(recv, L, r, int(glo[rank]), want_idx)
+
+
+class ShardedFastSLAM:
+    """One FastSLAM 1.0 filter over `world` ranks (13_fast_slam/fast_slam1.py:240-433): every rank runs
+    the per-particle step on its contiguous range, the ranks then agree on the weight sum and the
+    running sums in the reference's strictly sequential order, and resampled particles travel as
+    pose rows plus feature rows in two all-to-all exchanges.  The host combines the ranks' small
+    results (the exchanges are the ones of ShardedFilter's host-combined step)."""
+
+    def __init__(self, ctx, dist, rank, world, m_local, capacity):
+        self.ctx, self.dist, self.rank, self.world = ctx, dist, rank, world
+        ctx.fs_init(int(m_local), int(capacity))
+        self.coll = _Coll(dist, rank, world)
+        sizes = self.coll.allgather_bytes(np.int64(m_local).tobytes())
+        self.sizes = [int(np.frombuffer(x, np.int64)[0]) for x in sizes]
+        for n in self.sizes[:-1]:
+            if n % CHUNK:
+                raise ValueError("every rank but the last must hold a multiple of %d particles" % CHUNK)
+        self.firsts = [int(x) for x in np.concatenate([[0], np.cumsum(self.sizes)])]
+        self.m_total = self.firsts[-1]
+        ctx.shard_set(self.firsts[rank], self.m_total)
+        self.words = ctx.fs_row_words()
+        self.last_idx = None
+        self._plan = ShardedFilter._plan.__get__(self)   # same slicing rule as the particle filter
+
+    def _exact_running_sums(self, divisor, all_chunks):
+        """w /= divisor on every rank, then the strictly sequential running sum of the GLOBAL weight
+        vector, this rank's part left on the device (the record exchange of the particle filter)."""
+        ctx, co, rank, world = self.ctx, self.coll, self.rank, self.world
+        below = float(np.sum(np.concatenate(all_chunks[:rank]))) if rank else 0.0
+        k_total, nrec = ctx.shard_scan(divisor, below / divisor)
+        recs = ctx.shard_get_records(nrec)
+        parts = co.allgather_bytes(np.array([k_total, nrec], np.uint64).tobytes() + recs.tobytes(), cap=16 + 24 * 256)
+        k_tot = [int(np.frombuffer(p[:16], np.uint64)[0]) for p in parts]
+        n_rec = [int(np.frombuffer(p[:16], np.uint64)[1]) for p in parts]
+        p_off, f_off = [0] * world, [0] * world
+        for s in range(1, world):
+            p_off[s] = (p_off[s - 1] + k_tot[s - 1]) & 0xFFFFFFFFFFFFFFFF
+            f_off[s] = f_off[s - 1] + n_rec[s - 1]
+        glob = []
+        for s, p in enumerate(parts):
+            rs = np.frombuffer(p[16:], _lib.Context.RECORD_DTYPE).copy()
+            rs["P"] = rs["P"] + np.uint64(p_off[s])
+            glob.append(rs)
+        ctx.shard_finalize(np.concatenate(glob), p_off[rank], f_off[rank])
+
+    def step(self, v, omega, dt, alpha, truth_r, truth_phi, truth_valid, ints, normals, r, seed=0, want_idx=False):
+        """ints / normals: this rank's slice of the pre-drawn numbers (or None: device generators keyed
+        by the global particle index).  r = np.random.rand() * 1/M_total, identical on every rank."""
+        ctx, co, rank, world = self.ctx, self.coll, self.rank, self.world
+        ctx.fs_shard_kernel(v, omega, dt, alpha, truth_r, truth_phi, truth_valid, ints, normals, seed)
+        chunks = ctx.shard_weights(_lib.W_PRODUCT, 0.0)          # approximate offsets only
+        all_chunks = [np.frombuffer(x, np.float64) for x in co.allgather_bytes(chunks.tobytes())]
+        # sum_w exactly as `for m in range(M): sum_w += Y[m].w` forms it (:411-413)
+        self._exact_running_sums(1.0, all_chunks)
+        lasts = [np.frombuffer(x, np.float64)[0] for x in co.allgather_bytes(np.float64(ctx.fs_shard_last_sum()).tobytes())]
+        self.total = max(1e-8, float(lasts[-1]))                 # :415
+        self._exact_running_sums(self.total, all_chunks)         # w /= sum_w (:418) and c_i (:421-428)
+        M = self.m_total
+        m_edge = []
+        for d in range(world):
+            m_edge += [self.firsts[d], self.firsts[d + 1] - 1]
+        U = np.array([r + (m / M) for m in m_edge], np.float64)
+        gidx = np.minimum(co.allreduce_sum_i64(ctx.shard_count_below(U)), M - 1)   # the i < M-1 guard (:426)
+        lo, hi, send_counts, recv_counts, glo = self._plan(gidx)
+        n_send, L = int(sum(send_counts)), int(sum(recv_counts))
+        send = co.rows(n_send)
+        fsend = co.rows(n_send, self.words, co.torch.int64)
+        if n_send:
+            ctx.shard_pack(lo, hi, send.data_ptr())
+            ctx.fs_shard_pack(lo, hi, fsend.data_ptr())
+        recv = co.all_to_all_rows(send, send_counts, recv_counts)
+        frecv = co.all_to_all_rows(fsend, send_counts, recv_counts)
+        self.last_idx = ctx.shard_unpack_resample(recv.data_ptr(), L, r, int(glo[rank]), True)
+        ctx.fs_shard_unpack(frecv.data_ptr(), L, int(glo[rank]))
+        if not want_idx:
+            self.last_idx = None

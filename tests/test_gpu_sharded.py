@@ -213,3 +213,61 @@ def test_device_driven_step_falls_back_to_the_host_path_on_overflow():
     assert res["fallbacks"] == 1 and res["total"] == total
     assert np.array_equal(res["idx"], idx)
     assert np.array_equal(res["X"], Xr) and np.array_equal(res["w"], wr)
+
+
+# ---- FastSLAM over several ranks ------------------------------------------------------------
+def _fs_inputs(M, steps):
+    from oracle import fastslam_oracle as F
+    rng = np.random.RandomState(11)
+    lm = F.LANDMARKS
+    x_gt = [0, 0, 0]
+    out = []
+    for t in range(steps):
+        ut = [25, 0.001] if t != 2 else [25, -np.pi / 2 * 5]
+        x_gt = F.true_pose_step(x_gt, ut)
+        tm = F.true_measurements(x_gt, lm)
+        tr = np.array([float(a[0]) for a in tm]); tp = np.array([float(a[1]) for a in tm])
+        tv = np.array([a[2] for a in tm], np.uint8)
+        nv = int(tv.sum())
+        out.append((ut, tr, tp, tv, rng.randint(-1000, 1000, size=(M, 3, 12)).astype(np.int16), rng.randn(M, 2 * nv),
+                    rng.rand() / M))
+    return out
+
+
+def _fs_rank_fn(rank, world, dist, sizes, steps):
+    from oracle import fastslam_oracle as F
+    from slam_amd import _lib
+    from slam_amd.sharded import ShardedFastSLAM
+    M = sum(sizes)
+    first = sum(sizes[:rank])
+    sl = slice(first, first + sizes[rank])
+    ctx = _lib.Context(0, _lib.F64)
+    f = ShardedFastSLAM(ctx, dist, rank, world, sizes[rank], 16)
+    idx = []
+    for (ut, tr, tp, tv, ints, nrm, r) in _fs_inputs(M, steps):
+        f.step(ut[0], ut[1], F.DT, F.ALPHA, tr, tp, tv, ints[sl], nrm[sl], r, want_idx=True)
+        idx.append(f.last_idx)
+    st = ctx.fs_get_state()
+    st["idx"] = idx
+    return st
+
+
+@pytest.mark.parametrize("sizes", [(8192, 8192), (8192, 8192, 3000)])
+def test_fastslam_over_ranks_equals_one_context(sizes):
+    """FastSLAM with the particles split over ranks (gloo carries the exchanges, the ranks share the
+    box's GPU): ancestors and the whole particle state, feature slots included, equal the
+    single-context filter bit for bit after four steps."""
+    from oracle import fastslam_oracle as F
+    from slam_amd import _lib
+    M, steps = sum(sizes), 4
+    ref = _lib.Context(0, _lib.F64)
+    ref.fs_init(M, 16)
+    ref_idx = []
+    for (ut, tr, tp, tv, ints, nrm, r) in _fs_inputs(M, steps):
+        ref_idx.append(ref.fs_step(ut[0], ut[1], F.DT, F.ALPHA, tr, tp, tv, ints, nrm, r, want_idx=True))
+    want = ref.fs_get_state()
+    res = run_ranks(_fs_rank_fn, len(sizes), sizes, steps)
+    for t in range(steps):
+        assert np.array_equal(np.concatenate([x["idx"][t] for x in res]), ref_idx[t]), t
+    for k in ("pose", "w", "nfeat", "new_id", "f_m", "f_cov", "f_i", "f_w", "f_id"):
+        assert np.array_equal(np.concatenate([x[k] for x in res]), want[k]), k
