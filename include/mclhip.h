@@ -89,6 +89,16 @@ int mclhip_set_sensor(mclhip_ctx* ctx, const double* angles_deg, int B, double z
  * X_aos: [M][3] (x, y, theta); w: [M] or NULL (-> 1/M). */
 int mclhip_set_particles(mclhip_ctx* ctx, const double* X_aos, const double* w, int64_t M);
 
+/* Replaces MCLocalization.initialize (mc_localization.py:173-219) for particle
+ * counts at which the reference's Python rejection loop is not an option: M poses
+ * drawn on the device on free cells (value 255 after the reference's rounding) --
+ * x0 == NULL: uniform over [0, extent_x) x [0, extent_y), heading U[0, 2pi)
+ * (:176-196); else normal around x0[3] with sigma 0.1 * extent, heading
+ * N(x0[2], pi) (:197-219).  Same distribution as the reference, not numpy's
+ * stream; weights 1/M. */
+int mclhip_init_particles(mclhip_ctx* ctx, int64_t M, const double* x0, double extent_x, double extent_y,
+                          uint64_t seed);
+
 /* Replaces reads of self.X / self.w.  Any pointer may be NULL.
  * logw: sum_k log p_k of the last sample (-inf where the motion left the free space). */
 int mclhip_get_particles(mclhip_ctx* ctx, double* X_aos, double* w, double* logw);

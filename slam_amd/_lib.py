@@ -36,6 +36,7 @@ PROTOTYPES = {
     "mclhip_set_map": (C.c_int, [_ctx_p, _u8_p, C.c_int, C.c_int, C.c_double, C.c_double]),
     "mclhip_set_sensor": (C.c_int, [_ctx_p, _dbl_p, C.c_int, C.c_double, C.c_double, C.c_double, _dbl_p, C.c_double]),
     "mclhip_set_particles": (C.c_int, [_ctx_p, _dbl_p, _dbl_p, C.c_int64]),
+    "mclhip_init_particles": (C.c_int, [_ctx_p, C.c_int64, _dbl_p, C.c_double, C.c_double, C.c_uint64]),
     "mclhip_get_particles": (C.c_int, [_ctx_p, _dbl_p, _dbl_p, _dbl_p]),
     "mclhip_num_particles": (C.c_int64, [_ctx_p]),
     "mclhip_raycast": (C.c_int, [_ctx_p, _dbl_p, C.c_int64, _dbl_p, _i32_p]),
@@ -406,6 +407,11 @@ class Context:
         idx = np.empty(self.num_particles(), np.int64)
         self._ck(self.lib.mclhip_get_indices(self.h, _p(idx, _i64_p)), "mclhip_get_indices")
         return idx
+
+    def init_particles(self, M, x0, extent_x, extent_y, seed=0):
+        x = None if x0 is None else _f64(np.asarray(x0, np.float64).ravel(), (3,))
+        self._ck(self.lib.mclhip_init_particles(self.h, int(M), _p(x, _dbl_p), float(extent_x), float(extent_y),
+                                                int(seed)), "mclhip_init_particles")
 
     # grid (histogram) localisation ------------------------------------------
     def grid_set_map(self, grid, res_x, res_y, obstacle_below=200):

@@ -27,14 +27,13 @@ RayParams make_ray_params(const mclhip_ctx* c) {
   P.nbr_off = c->nbr_off;
   P.nbr_cells = c->nbr_cells;
   P.ETW = c->ETW; P.ETH = c->ETH; P.rtx = c->rtx; P.rty = c->rty;
-  P.TW = c->TW; P.TH = c->TH; P.W = c->W; P.H = c->H;
+  P.W = c->W;
   P.res_xf = (float)c->res_x; P.res_yf = (float)c->res_y;
   P.res_x = c->res_x; P.res_y = c->res_y;
   P.z_max = c->z_max;
   P.r2max = std::pow(c->z_max, 2.0);  // max_sensor_range**2 (mc_localization.py:127)
   P.B = c->B; P.NB = c->NB;
-  P.tab_sorted = c->tab_sorted; P.tab_orig = c->tab_orig; P.perm = c->perm; P.lut = c->lut;
-  P.ring = c->ring; P.n_ring = c->n_ring;
+  P.tab_sorted = c->tab_sorted; P.perm = c->perm; P.lut = c->lut;
   P.ts_min = c->ts_min; P.ts_max = c->ts_max; P.inv_bw = c->inv_bw;
   P.relx = c->relx; P.G = c->G; P.ext_min = c->ext_min;
   P.half = c->half;
@@ -443,6 +442,29 @@ int mclhip_set_particles(mclhip_ctx* c, const double* X, const double* w, int64_
   MCL_HIP(c, hipMemcpy(c->w[0], w, M * sizeof(double), hipMemcpyHostToDevice));
   std::vector<double> z(M, 0.0);
   MCL_HIP(c, hipMemcpy(c->logw, z.data(), M * sizeof(double), hipMemcpyHostToDevice));
+  return MCLHIP_OK;
+}
+
+int mclhip_init_particles(mclhip_ctx* c, int64_t M, const double* x0, double extent_x, double extent_y, uint64_t seed) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, true, false, false));
+  if (M <= 0 || !(extent_x > 0) || !(extent_y > 0)) return fail(c, MCLHIP_E_ARG, "M <= 0 or empty extent");
+  if (M > ((int64_t)1 << 31)) return fail(c, MCLHIP_E_LIMIT, "at most 2^31 particles per context");
+  MCL_TRY(ensure_capacity(c, M));
+  c->M = M;
+  c->cur = 0;
+  const double al[6] = {0, 0, 0, 0, 0, 0};
+  MotionParams mp = make_motion_params(c, 0.0, 0.0, 0.0, al, 0, seed);
+  if (!c->counters) MCL_TRY(dev_alloc(c, &c->counters, 16 * sizeof(uint32_t)));
+  MCL_HIP(c, hipMemsetAsync(c->counters, 0, sizeof(uint32_t), c->stream));
+  MCL_TRY(launch_init_particles(c, c->px[0], c->py[0], c->pth[0], M, mp, x0 ? 1 : 0, extent_x, extent_y, x0, seed, c->counters));
+  std::vector<double> hw(M, 1.0 / (double)M), z(M, 0.0);   // np.ones(M)/M (mc_localization.py:41)
+  MCL_HIP(c, hipMemcpyAsync(c->w[0], hw.data(), M * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  MCL_HIP(c, hipMemcpyAsync(c->logw, z.data(), M * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  uint32_t failed = 0;
+  MCL_HIP(c, hipMemcpyAsync(&failed, c->counters, sizeof(failed), hipMemcpyDeviceToHost, c->stream));
+  MCL_HIP(c, hipStreamSynchronize(c->stream));
+  if (failed) return fail(c, MCLHIP_E_STATE, "no free cell found for some particles (is any cell of the map 255 inside the extent?)");
   return MCLHIP_OK;
 }
 

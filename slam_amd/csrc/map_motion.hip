@@ -179,6 +179,69 @@ __global__ __launch_bounds__(256) void motion_kernel(T* __restrict__ xs, T* __re
   pm[i] = on_free_cell((double)sx, (double)sy, mp) ? 1 : 0;
 }
 
+// Initial particle cloud drawn on the device (mc_localization.py:173-219): rejection sampling of
+// (x, y) until the pose rounds to a free cell -- uniform over [0, ext_x) x [0, ext_y) with heading
+// U[0, 2pi), or normal around x0 with sigma 0.1 * extent and heading N(x0.theta, pi).  The draws
+// come from the counter-based generator keyed by the global particle index, not from numpy's
+// stream, so the cloud has the reference's distribution, not its values.
+struct InitParams {
+  int gaussian;
+  double ext_x, ext_y, x0, y0, th0;
+  uint64_t seed;
+  int max_tries;
+};
+
+__device__ inline double uniform01(uint32_t hi, uint32_t lo) {   // 53-bit uniform in [0, 1)
+  return (double)((((uint64_t)hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void init_particles_kernel(T* __restrict__ xs, T* __restrict__ ys, T* __restrict__ ths,
+                                                             int64_t n, MotionParams mp, InitParams ip,
+                                                             uint32_t* __restrict__ failures) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t gi = (uint64_t)(mp.index0 + i);
+  double x = 0.0, y = 0.0, a = 0.0;
+  bool ok = false;
+  for (int t = 0; t < ip.max_tries && !ok; ++t) {
+    uint32_t c[4] = {(uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)t, 0x494e4954u};
+    philox4x32(c, (uint32_t)ip.seed, (uint32_t)(ip.seed >> 32));
+    uint32_t d[4] = {(uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)t, 0x494e4955u};
+    philox4x32(d, (uint32_t)ip.seed, (uint32_t)(ip.seed >> 32));
+    const double u1 = uniform01(c[0], c[1]), u2 = uniform01(c[2], c[3]);
+    const double u3 = uniform01(d[0], d[1]), u4 = uniform01(d[2], d[3]);
+    if (ip.gaussian) {   // two Box-Muller pairs: (x, y) and the heading
+      const double r1 = sqrt(-2.0 * log(1.0 - u1)), r2 = sqrt(-2.0 * log(1.0 - u3));
+      x = r1 * cos(2.0 * M_PI * u2) * ip.ext_x * 0.1 + ip.x0;
+      y = r1 * sin(2.0 * M_PI * u2) * ip.ext_y * 0.1 + ip.y0;
+      a = r2 * cos(2.0 * M_PI * u4) * M_PI + ip.th0;
+    } else {
+      x = u1 * ip.ext_x;
+      y = u2 * ip.ext_y;
+      a = u3 * M_PI * 2.0;
+    }
+    ok = on_free_cell(x, y, mp);
+  }
+  if (!ok) atomicAdd(failures, 1u);
+  xs[i] = (T)x; ys[i] = (T)y; ths[i] = (T)a;
+}
+
+int launch_init_particles(mclhip_ctx* c, void* x, void* y, void* th, int64_t n, const MotionParams& mp, int gaussian,
+                          double ext_x, double ext_y, const double* x0, uint64_t seed, uint32_t* d_failures) {
+  InitParams ip;
+  ip.gaussian = gaussian; ip.ext_x = ext_x; ip.ext_y = ext_y;
+  ip.x0 = x0 ? x0[0] : 0.0; ip.y0 = x0 ? x0[1] : 0.0; ip.th0 = x0 ? x0[2] : 0.0;
+  ip.seed = seed; ip.max_tries = 4096;
+  dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (c->dtype == MCLHIP_F32)
+    hipLaunchKernelGGL(init_particles_kernel<float>, grid, block, 0, c->stream, (float*)x, (float*)y, (float*)th, n, mp, ip, d_failures);
+  else
+    hipLaunchKernelGGL(init_particles_kernel<double>, grid, block, 0, c->stream, (double*)x, (double*)y, (double*)th, n, mp, ip, d_failures);
+  MCL_HIP(c, hipGetLastError());
+  return MCLHIP_OK;
+}
+
 int launch_motion(mclhip_ctx* c, void* x, void* y, void* th, uint8_t* pm, int64_t n, const MotionParams& mp,
                   const int16_t* d_noise, int dtype) {
   if (n <= 0) return MCLHIP_OK;

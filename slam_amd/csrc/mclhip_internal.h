@@ -26,21 +26,18 @@ struct RayParams {
   const uint32_t* nbr_cells; // per tile: the obstacle cells (row << 16 | col) of every tile that can hold a cell
                              // within z_max of a point of that tile, nearest tile first
   int ETW, ETH, rtx, rty;    // the tile grid is extended by rtx / rty tiles on each side (poses just outside the map)
-  int TW, TH, W, H;
+  int W;                     // map width in cells (hit cells are reported as row * W + col)
   float res_xf, res_yf;  // float32 cell size: cell-centre coordinates are float32 products
   double res_x, res_y;
   double z_max, r2max;
   int B, NB;
   const double* tab_sorted;  // beam angles in radians (deg*pi/180), ascending
-  const double* tab_orig;    // the same, in the caller's beam order
   const uint16_t* perm;      // sorted position -> caller's beam index
   const uint16_t* lut;       // bucket -> first position of the extended table at or after the bucket's lower edge
   const float* relx;         // [G + B] extended table: float32(angle - smallest angle); the first G entries are
                              // the last G beams moved down one turn (their images across the 0 / 2pi seam)
   int G;                     // number of such images
   double ext_min;            // relx[0] as float64 (<= 0): lower end of the bucket index
-  const uint16_t* ring;      // tile offsets around the particle's tile, nearest first: (dty+128) << 8 | (dtx+128)
-  int n_ring;
   double ts_min, ts_max, inv_bw;
   double half, two_pi_lo, two_pi_hi;
   // beam mixture
@@ -200,6 +197,8 @@ int launch_nbr_count(mclhip_ctx* c, uint32_t* d_cnt);
 int launch_nbr_fill(mclhip_ctx* c);
 int launch_motion(mclhip_ctx* c, void* x, void* y, void* th, uint8_t* pm, int64_t n, const MotionParams& mp,
                   const int16_t* d_noise, int dtype);
+int launch_init_particles(mclhip_ctx* c, void* x, void* y, void* th, int64_t n, const MotionParams& mp, int gaussian,
+                          double ext_x, double ext_y, const double* x0, uint64_t seed, uint32_t* d_failures);
 int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, const uint8_t* pm, int64_t n,
                    int dtype, double* w_out, double* logw_out, double* ranges_out, int32_t* hits_out,
                    const double* range_noise = nullptr);

@@ -515,14 +515,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? MCL_RAY_WAVES : 4)) void ray
 #endif
 }
 
-static size_t ray_lds_bytes(int B, int G, int NB, int n_ring, bool aux) {
+static size_t ray_lds_bytes(int B, int G, int NB, bool aux) {
   const int NXP = B + G + kGroup;
   size_t s = (size_t)3 * B * sizeof(double);
   s += (size_t)kWavesPerBlock * NXP * sizeof(unsigned long long) * (aux ? 2 : 1);
   s += (size_t)kWavesPerBlock * kWaveScratch * sizeof(unsigned int);
   s += (size_t)NXP * sizeof(float);
   s += ((size_t)B + NB + 2) * sizeof(unsigned short);
-  (void)n_ring;
   return (s + 15) & ~(size_t)15;
 }
 
@@ -534,7 +533,7 @@ int launch_grid_update(mclhip_ctx* c, const double* d_x, const double* d_y, cons
   RayParams P = make_ray_params(c);
   P.g_inv_perm = c->inv_perm;
   P.g_cell = d_cell; P.g_D = n_dir; P.g_B0 = beams_per_dir; P.g_pk_pred = pk_pred; P.g_pk = pk;
-  const size_t lds = ray_lds_bytes(P.B, P.G, P.NB, P.n_ring, false);
+  const size_t lds = ray_lds_bytes(P.B, P.G, P.NB, false);
   if (lds > 160 * 1024) return fail(c, MCLHIP_E_LIMIT, "heading x beam table does not fit the kernel's LDS budget");
   auto kern = raycast_kernel<double, false, false, true>;
   if (lds > 48 * 1024)
@@ -555,10 +554,10 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
   RayParams P = make_ray_params(c);
   P.range_noise = range_noise;
   const bool stage = ranges_out != nullptr;
-  const size_t lds = ray_lds_bytes(P.B, P.G, P.NB, P.n_ring, stage || product);
+  const size_t lds = ray_lds_bytes(P.B, P.G, P.NB, stage || product);
   if (lds > 64 * 1024) return fail(c, MCLHIP_E_LIMIT, "beam table does not fit the kernel's LDS budget");
   int64_t blocks = (n + kWavesPerBlock - 1) / kWavesPerBlock;
-  static const int64_t max_blocks = getenv("MCLHIP_RAY_BLOCKS") ? atoll(getenv("MCLHIP_RAY_BLOCKS")) : 256 * 8 * 4;  // each wave loops over particles
+  const int64_t max_blocks = 256 * 8 * 4;   // 8192 blocks of four waves; each wave loops over particles
   if (blocks > max_blocks) blocks = max_blocks;
   dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
   if (stage) {

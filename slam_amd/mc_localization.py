@@ -224,9 +224,16 @@ class MCLocalization:
         self._push_config()
         return self._ctx.raycast(poses, want_hits=True)
 
-    def initialize(self, x0=None):
+    def initialize(self, x0=None, on_device=False, seed=0):
         """Rejection-sample M poses on free cells (mc_localization.py:173-219); consumes
-        np.random exactly as the reference does."""
+        np.random exactly as the reference does.  on_device=True draws the cloud on the GPU instead
+        (same distribution, the device's own generator): for particle counts at which a Python loop
+        per particle is not an option."""
+        if on_device:
+            self._push_config()
+            self._ctx.init_particles(self.M, x0, max_x, max_y, seed)
+            self._host_fresh, self._dev_fresh = False, True
+            return
         g = np.asarray(self.map)
         H, W = g.shape
         X = np.zeros([self.M, 3])

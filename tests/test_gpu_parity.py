@@ -328,3 +328,39 @@ def test_augmented_dropin_class_follows_reference_run():
         mcl.resample()
         assert np.array_equal(mcl.last_injected, s["inj_rows"])
         assert rel_err(mcl.X, s["X_out"]) < 1e-12
+
+
+def test_device_side_initialisation_has_the_reference_distribution():
+    """mclhip_init_particles (mc_localization.py:173-219 on the device): every pose rounds to a free
+    cell; the uniform cloud covers the free space evenly; the normal cloud has the reference's
+    moments.  Statistical parity only: the draws are the device generator's, not numpy's."""
+    from slam_amd.mc_localization import MCLocalization, max_x, max_y
+    grid = np.load(os.path.join(GOLDEN, "grid_map_g.npy"))
+    M = 200000
+    mcl = MCLocalization(np.array([3.0, 4.5, 0.0]), grid, M=M)
+    mcl.initialize(on_device=True, seed=5)
+    X = mcl.X.copy()
+    assert X.shape == (M, 3) and np.all(np.isfinite(X))
+    assert np.all(O.free_cell(X[:, 0], X[:, 1], grid) == 1.0)
+    assert X[:, 2].min() >= 0 and X[:, 2].max() < 2 * np.pi and abs(X[:, 2].mean() - np.pi) < 0.02
+    # even coverage: particle counts per free cell are Poisson with the same mean
+    u = np.trunc(X[:, 0] / O.RES_X + 0.5).astype(int)
+    v = np.trunc(X[:, 1] / O.RES_Y + 0.5).astype(int)
+    cnt = np.zeros(grid.shape, int)
+    np.add.at(cnt, (v, u), 1)
+    free = grid == 255
+    lam = M / free.sum()
+    assert abs(cnt[free].mean() - lam) < 1e-9 and abs(cnt[free].var() / lam - 1.0) < 0.1
+    assert np.allclose(mcl.w, 1.0 / M)
+    # normal cloud on an all-free map: moments of the proposal itself
+    mcl2 = MCLocalization(np.array([7.0, 8.0, 0.5]), np.full((100, 100), 255, np.uint8), M=M)
+    mcl2.initialize(np.array([7.0, 8.0, 0.5]), on_device=True, seed=6)
+    Y = mcl2.X
+    inside = (Y[:, 0] > 0) & (Y[:, 1] > 0)
+    assert inside.all()
+    assert abs(Y[:, 2].mean() - 0.5) < 0.03 and abs(Y[:, 2].std() - np.pi) < 0.03
+    assert abs(np.median(Y[:, 0]) - 7.0) < 0.03 and abs(np.median(Y[:, 1]) - 8.0) < 0.03
+    # and it feeds the filter like any other cloud
+    mcl.sample([1.5, 0], 0.1)
+    mcl.resample()
+    assert np.isfinite(mcl.w).all()
