@@ -392,7 +392,7 @@ int mclhip_grid_update(mclhip_ctx* c, const double* z_meas, float* sum_out) {
   MCL_HIP(c, hipMemcpy(c->zmeas_stage, tiled.data(), tiled.size() * sizeof(double), hipMemcpyHostToDevice));
   const int64_t n = (int64_t)c->H * c->W * D;
   Timer tm(c, 4);
-  G_TRY(launch_beam_table(c));
+  G_TRY(launch_grid_beam_table(c));
   MCL_HIP(c, hipMemsetAsync(c->gl_pk, 0, n * sizeof(float), c->stream));   // cells below the threshold (robot.py:302)
   G_TRY(launch_grid_update(c, c->gl_x, c->gl_y, c->gl_th, c->gl_cell, c->gl_nfree, D, B0, c->gl_pk_pred, c->gl_pk));
   const int64_t nchunks = (n + kSumChunk - 1) / kSumChunk;

@@ -188,6 +188,7 @@ int fail(mclhip_ctx* c, int code, const std::string& msg);
 // kernels launchers, one per stage; all enqueue on c->stream
 int launch_build_tiles(mclhip_ctx* c, const uint8_t* d_map);
 int launch_beam_table(mclhip_ctx* c);
+int launch_grid_beam_table(mclhip_ctx* c);
 int set_sensor_table(mclhip_ctx* c, const double* tab_rad, int B, double z_max, double sigma_hit, double lambda_short,
                      const double w4[4], double half);
 int launch_grid_update(mclhip_ctx* c, const double* d_x, const double* d_y, const double* d_th, const int32_t* d_cell,

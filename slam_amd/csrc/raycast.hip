@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? MCL_RAY_WAVES : 4)) void ray
     s_perm[k] = P.perm[k];
     if (!STAGE) {
       s_zt[k] = P.zt[k];
-      if (!GRID) s_el[k] = P.etalam[k];
+      s_el[k] = P.etalam[k];   // GRID mode: exp(-lambda * z_meas) of the entry
     }
   }
   for (int k = threadIdx.x; k < NXP; k += blockDim.x) s_relx[k] = (k < P.G + B) ? P.relx[k] : 1.0e30f;  // padding: beyond any window
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? MCL_RAY_WAVES : 4)) void ray
         double p_short = 0.0;
         if ((0.0 <= xm) && (xm <= z)) {
           const double eta = 1.0 / (1.0 - exp(-P.lambda * z));
-          p_short = eta * P.lambda * exp(-P.lambda * xm);
+          p_short = eta * P.lambda * s_el[k];   // exp(-lambda * z_meas), tabulated per entry
         }
         const double p_max = (fabs(xm - P.z_max) < 1e-6) ? 1.0 : 0.0;
         const double p_rand = in_range ? P.p_rand : 0.0;
