@@ -526,6 +526,14 @@ class Context:
         self._ck(self.lib.mclhip_fs_shard_unpack(self.h, C.c_void_p(rows_ptr), int(L), int(row0_global)),
                  "mclhip_fs_shard_unpack")
 
+    def fs_feature_counts(self):
+        """Features per particle and the next feature id of every particle (no feature data is copied)."""
+        M = self.fs_M
+        nfeat, new_id = np.empty(M, np.int32), np.empty(M, np.int32)
+        self._ck(self.lib.mclhip_fs_get_state(self.h, None, None, _p(nfeat, _i32_p), _p(new_id, _i32_p), None, None, None,
+                                              None, None), "mclhip_fs_get_state")
+        return nfeat, new_id
+
     def fs_get_state(self):
         M, F = self.fs_M, self.fs_cap
         out = {"pose": np.empty((M, 3)), "w": np.empty(M), "nfeat": np.empty(M, np.int32), "new_id": np.empty(M, np.int32),

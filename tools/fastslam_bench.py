@@ -16,10 +16,18 @@ for t in range(steps):
     slam.control(ut)
     t_all.append(time.perf_counter() - t0)
     print("step", t, "%.1f ms" % (t_all[-1] * 1e3), flush=True)
-st = slam._ctx.fs_get_state() if M <= (1 << 18) else None
+nfeat, _ = slam._ctx.fs_feature_counts()
+mean_features = float(nfeat.mean())
 ms = float(np.median(t_all[1:])) * 1e3
+# HBM bytes a step cannot avoid: every live feature slot (64 B) is read and written once by the filter step and
+# read and written once more by the resampling gather
+algo_bytes = M * mean_features * 64.0 * 4
 out = {"metric": "FastSLAM 1.0 particle-steps per second", "particles": M, "landmarks": NL, "value": M / (ms * 1e-3),
-       "unit": "particle-steps/s", "ms_per_step": ms, "mean_features": None if st is None else float(st["nfeat"].mean())}
+       "unit": "particle-steps/s", "ms_per_step": ms, "mean_features": mean_features,
+       "roofline": {"bound": "hbm", "kernel": "whole step (predict, draw, associate, apply, decay, resample + gather)",
+                    "achieved": algo_bytes / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                    "frac": algo_bytes / (ms * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_step": algo_bytes,
+                    "traffic": None}}
 if os.environ.get("FS_CPU", "1") == "1":
     # CPU baseline: the numpy restatement on 64 particles of the same landmark field (one core)
     from oracle import fastslam_oracle as F
