@@ -47,7 +47,8 @@ RayParams make_ray_params(const mclhip_ctx* c) {
   P.p_rand = 1 / c->z_max;                               // range_sensor.py:64
   P.range_noise = nullptr;
   P.stamps = c->stamps;
-  P.g_cell = nullptr; P.g_inv_perm = nullptr; P.g_pk_pred = nullptr; P.g_pk = nullptr; P.g_D = 0; P.g_B0 = 0;
+  P.g_cell = nullptr; P.g_pk_pred = nullptr; P.g_pk = nullptr; P.g_D = 0; P.g_B0 = 0;
+  P.g_NE = 0; P.g_cls = nullptr; P.g_cls_first = nullptr; P.g_member = nullptr; P.g_mbeta = nullptr;
   P.no_obstacles = c->n_obstacles == 0 ? 1 : 0;
   return P;
 }
@@ -281,7 +282,7 @@ void mclhip_destroy(mclhip_ctx* c) {
                   c->px[0], c->px[1], c->py[0], c->py[1], c->pth[0], c->pth[1], c->w[0], c->w[1], c->logw, c->pm,
                   c->sx, c->sy, c->sth, c->sw, c->chunk_sums, c->scal, c->cdf_approx, c->cdf_exact, c->kscan,
                   c->fscan, c->blk_a, c->blk_b, c->irr, c->bases, c->idx, c->noise, c->counters, c->range_noise, c->inj_rows, c->stamps,
-                  c->inj_poses, c->g_records, c->g_bases, c->gl_mask, c->gl_x, c->gl_y, c->gl_th, c->gl_cell, c->gl_pk, c->gl_pk_pred, c->gl_K, c->gl_part,
+                  c->inj_poses, c->g_records, c->g_bases, c->gl_mask, c->gl_x, c->gl_y, c->gl_th, c->gl_cell, c->gl_pk, c->gl_pk_pred, c->gl_K, c->gl_part, c->gl_cls, c->gl_cls_first, c->gl_member, c->gl_mbeta, c->gl_zt, c->gl_el, c->gl_zm,
                   c->rows_send, c->rows_recv, c->small_d, c->small_i};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);

@@ -291,7 +291,8 @@ int mclhip_grid_set_sensor(mclhip_ctx* c, const double* angles_deg, int B0, int 
   if (!c->gl_mask) return fail(c, MCLHIP_E_STATE, "no grid map: call mclhip_grid_set_map first");
   if (!angles_deg || !w4 || B0 <= 0 || n_dir <= 0) return fail(c, MCLHIP_E_ARG, "angles/w4 NULL, no beams or no headings");
   if ((int64_t)B0 * n_dir > kMaxBeams) return fail(c, MCLHIP_E_LIMIT, "headings x beams is limited to 1024");
-  std::vector<double> tab((size_t)B0 * n_dir);
+  const int NE = B0 * n_dir;
+  std::vector<double> tab((size_t)NE);
   for (int d = 0; d < n_dir; ++d) {
     const double theta = (double)d * res_theta_deg * M_PI / 180.0;   // robot.py:289
     for (int k = 0; k < B0; ++k) {
@@ -299,7 +300,50 @@ int mclhip_grid_set_sensor(mclhip_ctx* c, const double* angles_deg, int B0, int 
       tab[(size_t)d * B0 + k] = angles_deg[k] * M_PI / 180.0 + theta;   // robot.py:252
     }
   }
-  G_TRY(set_sensor_table(c, tab.data(), B0 * n_dir, z_max, sigma_hit, lambda_short, w4, half));
+  // Many (heading, beam) pairs point the same way: with headings every 5 degrees and beams every 15 there are
+  // 72 absolute bearings for 936 pairs.  Entries whose angles agree modulo one turn to within 1e-9 rad form a
+  // class; the sector query runs on the class table, and only a cell within the float32 uncertainty of a
+  // sector edge (where the last bits of an entry's own angle decide) is tested entry by entry.  The
+  // reference's test recognises one turn of difference and no more (robot.py:256-258): the sector of an angle
+  // in [0, 2pi) is the full window around it, and so is that of an angle one turn higher or lower as long as
+  // its window does not reach past 4pi or -2pi (there the reference's own window is cut off); angles beyond
+  // that are refused.
+  const double two_pi = M_PI * 2;
+  std::vector<double> red(NE);
+  for (int e = 0; e < NE; ++e) {
+    if (!(tab[e] > -two_pi + half + 1e-6 && tab[e] < 2 * two_pi - half - 1e-6))
+      return fail(c, MCLHIP_E_LIMIT, "heading + beam angle (and its sector) must lie within (-2pi, 4pi)");
+    double u = tab[e] - two_pi * std::floor(tab[e] / two_pi);
+    if (u >= two_pi) u -= two_pi;
+    if (u < 0) u = 0;
+    red[e] = u;
+  }
+  std::vector<uint16_t> order(NE);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](uint16_t a, uint16_t b) { return red[a] < red[b]; });
+  std::vector<double> centre, mbeta(NE);
+  std::vector<uint16_t> cls(NE), first, member(NE);
+  for (int m = 0; m < NE; ++m) {
+    const int e = order[m];
+    if (centre.empty() || red[e] - centre.back() > 1e-9) { centre.push_back(red[e]); first.push_back((uint16_t)m); }
+    cls[e] = (uint16_t)(centre.size() - 1);
+    member[m] = (uint16_t)e;
+    mbeta[m] = tab[e];
+  }
+  first.push_back((uint16_t)NE);
+  G_TRY(set_sensor_table(c, centre.data(), (int)centre.size(), z_max, sigma_hit, lambda_short, w4, half));
+  c->gl_NE = NE;
+  G_TRY(galloc(c, &c->gl_cls, NE * sizeof(uint16_t)));
+  G_TRY(galloc(c, &c->gl_cls_first, first.size() * sizeof(uint16_t)));
+  G_TRY(galloc(c, &c->gl_member, NE * sizeof(uint16_t)));
+  G_TRY(galloc(c, &c->gl_mbeta, NE * sizeof(double)));
+  G_TRY(galloc(c, &c->gl_zt, NE * sizeof(double)));
+  G_TRY(galloc(c, &c->gl_el, NE * sizeof(double)));
+  G_TRY(galloc(c, &c->gl_zm, B0 * sizeof(double)));
+  MCL_HIP(c, hipMemcpy(c->gl_cls, cls.data(), NE * sizeof(uint16_t), hipMemcpyHostToDevice));
+  MCL_HIP(c, hipMemcpy(c->gl_cls_first, first.data(), first.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  MCL_HIP(c, hipMemcpy(c->gl_member, member.data(), NE * sizeof(uint16_t), hipMemcpyHostToDevice));
+  MCL_HIP(c, hipMemcpy(c->gl_mbeta, mbeta.data(), NE * sizeof(double), hipMemcpyHostToDevice));
   c->gl_D = n_dir; c->gl_B0 = B0; c->gl_res_theta = res_theta_deg;
   c->gl_angles_deg.assign(angles_deg, angles_deg + B0);
   const size_t n = (size_t)c->H * c->W * n_dir;
@@ -386,13 +430,10 @@ int mclhip_grid_update(mclhip_ctx* c, const double* z_meas, float* sum_out) {
   if (!z_meas) return fail(c, MCLHIP_E_ARG, "z_meas is NULL");
   G_TRY(build_ring_table(c));
   const int D = c->gl_D, B0 = c->gl_B0;
-  std::vector<double> tiled((size_t)D * B0);
-  for (int d = 0; d < D; ++d)
-    for (int k = 0; k < B0; ++k) tiled[(size_t)d * B0 + k] = z_meas[k];
-  MCL_HIP(c, hipMemcpy(c->zmeas_stage, tiled.data(), tiled.size() * sizeof(double), hipMemcpyHostToDevice));
+  MCL_HIP(c, hipMemcpy(c->gl_zm, z_meas, B0 * sizeof(double), hipMemcpyHostToDevice));
   const int64_t n = (int64_t)c->H * c->W * D;
   Timer tm(c, 4);
-  G_TRY(launch_grid_beam_table(c));
+  G_TRY(launch_grid_beam_table(c, c->gl_zm, B0, c->gl_NE, c->gl_zt, c->gl_el));
   MCL_HIP(c, hipMemsetAsync(c->gl_pk, 0, n * sizeof(float), c->stream));   // cells below the threshold (robot.py:302)
   G_TRY(launch_grid_update(c, c->gl_x, c->gl_y, c->gl_th, c->gl_cell, c->gl_nfree, D, B0, c->gl_pk_pred, c->gl_pk));
   const int64_t nchunks = (n + kSumChunk - 1) / kSumChunk;

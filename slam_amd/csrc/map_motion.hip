@@ -116,18 +116,18 @@ __global__ void beam_table_kernel(const double* __restrict__ zmeas, const uint16
 // histogram filter: the measured range is the first argument of compute_px there, so what is
 // constant per table entry is exp(-lambda * z_meas) (range_sensor.py:50); it goes where the
 // particle filter keeps eta * lambda
-__global__ void grid_beam_table_kernel(const double* __restrict__ zmeas, const uint16_t* __restrict__ perm, int B,
-                                       double lambda, double* __restrict__ zt, double* __restrict__ eshort) {
-  int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= B) return;
-  const double z = zmeas[perm[k]];
-  zt[k] = z;
-  eshort[k] = exp(-lambda * z);
+__global__ void grid_beam_table_kernel(const double* __restrict__ zmeas, int B0, int NE, double lambda,
+                                       double* __restrict__ zt, double* __restrict__ eshort) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;   // entry e = heading * B0 + beam
+  if (e >= NE) return;
+  const double z = zmeas[e % B0];
+  zt[e] = z;
+  eshort[e] = exp(-lambda * z);
 }
 
-int launch_grid_beam_table(mclhip_ctx* c) {
-  hipLaunchKernelGGL(grid_beam_table_kernel, dim3((c->B + 63) / 64), dim3(64), 0, c->stream, c->zmeas_stage, c->perm, c->B,
-                     c->lambda, c->zt, c->etalam);
+int launch_grid_beam_table(mclhip_ctx* c, const double* zmeas, int B0, int NE, double* zt, double* eshort) {
+  hipLaunchKernelGGL(grid_beam_table_kernel, dim3((NE + 63) / 64), dim3(64), 0, c->stream, zmeas, B0, NE, c->lambda, zt,
+                     eshort);
   MCL_HIP(c, hipGetLastError());
   return MCLHIP_OK;
 }

@@ -53,10 +53,14 @@ struct RayParams {
   unsigned long long* stamps;  // profiling build only: cycles per kernel section
   // histogram-filter update (one pose per free grid cell)
   const int32_t* g_cell;       // flat cell index of pose p
-  const uint16_t* g_inv_perm;  // sorted-table position of caller-order entry e
   const double* g_pk_pred;     // [H*W*D]
   float* g_pk;                 // [H*W*D]
   int g_D, g_B0;               // headings, beams per heading
+  int g_NE;                    // entries (headings x beams); the beam table proper holds their classes
+  const uint16_t* g_cls;       // [NE] class of entry e
+  const uint16_t* g_cls_first; // [B + 1]
+  const uint16_t* g_member;    // [NE] entries by class
+  const double* g_mbeta;       // [NE] exact table angle of g_member[m]
 };
 
 struct MotionParams {
@@ -162,6 +166,15 @@ struct mclhip_ctx {
   double* gl_pk_pred = nullptr;     // [H*W*D] prediction
   double* gl_K = nullptr;           // motion-model coefficients of the current control
   float* gl_part = nullptr;         // float32 chunk sums + total
+  // (heading, beam) entries of the update and the classes of entries that share an absolute bearing
+  int gl_NE = 0;                    // entries = headings x beams
+  uint16_t* gl_cls = nullptr;       // [NE] class (position in the sorted class table) of entry e = d * B0 + k
+  uint16_t* gl_cls_first = nullptr; // [classes + 1] start of each class in gl_member / gl_mbeta
+  uint16_t* gl_member = nullptr;    // [NE] entries grouped by class
+  double* gl_mbeta = nullptr;       // [NE] their table angles exactly as robot.py:252 forms them (not reduced)
+  double* gl_zt = nullptr;          // [NE] measured range of the entry's beam
+  double* gl_el = nullptr;          // [NE] exp(-lambda * z_meas)
+  double* gl_zm = nullptr;          // [B0] staged measurement
   std::vector<double> gl_angles_deg;
 
   void* fs = nullptr;               // FastSLAM storage (fastslam.hip owns the type)
@@ -188,7 +201,7 @@ int fail(mclhip_ctx* c, int code, const std::string& msg);
 // kernels launchers, one per stage; all enqueue on c->stream
 int launch_build_tiles(mclhip_ctx* c, const uint8_t* d_map);
 int launch_beam_table(mclhip_ctx* c);
-int launch_grid_beam_table(mclhip_ctx* c);
+int launch_grid_beam_table(mclhip_ctx* c, const double* zmeas, int B0, int NE, double* zt, double* eshort);
 int set_sensor_table(mclhip_ctx* c, const double* tab_rad, int B, double z_max, double sigma_hit, double lambda_short,
                      const double w4[4], double half);
 int launch_grid_update(mclhip_ctx* c, const double* d_x, const double* d_y, const double* d_th, const int32_t* d_cell,

@@ -134,41 +134,53 @@ __device__ __attribute__((noinline)) double slow_log(double v) { return log(v); 
 #ifndef MCL_RAY_WAVES
 #define MCL_RAY_WAVES 6
 #endif
-template <typename T, bool STAGE, bool PRODUCT, bool GRID = false>
-__global__ __launch_bounds__(256, (sizeof(T) == 4 ? MCL_RAY_WAVES : 4)) void raycast_kernel(
+// WPB: wavefronts per block.  Four for the particle filter; the histogram filter's table (all headings x
+// beams) makes the per-wave LDS array large, and more waves behind one copy of the block-wide tables is
+// what lifts its occupancy.
+template <typename T, bool STAGE, bool PRODUCT, bool GRID = false, int WPB = kWavesPerBlock>
+__global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (sizeof(T) == 4 ? MCL_RAY_WAVES : 4))) void raycast_kernel(
     RayParams P, const T* __restrict__ xs, const T* __restrict__ ys, const T* __restrict__ ths,
     const uint8_t* __restrict__ pm, int64_t n, double* __restrict__ w_out, double* __restrict__ logw_out,
     double* __restrict__ ranges_out, int32_t* __restrict__ hits_out) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int B = P.B, NB = P.NB;
+  // GRID: the beam table holds the classes of (heading, beam) entries that share a bearing; NE entries
+  const int NE = GRID ? P.g_NE : 0;
+  const int NT = GRID ? NE : B;                                   // rows of the per-beam mixture tables
   // block-wide tables
   double* s_ts = reinterpret_cast<double*>(smem);                 // [B] sorted beam angles
-  double* s_zt = s_ts + B;                                        // [B] measured range, sorted order
-  double* s_el = s_zt + B;                                        // [B] eta*lambda, sorted order
-  unsigned long long* s_rmin_all = reinterpret_cast<unsigned long long*>(s_el + B);
+  double* s_zt = s_ts + B;                                        // [NT] measured range (sorted order; GRID: entry order)
+  double* s_el = s_zt + NT;                                       // [NT] eta*lambda (GRID: exp(-lambda * z_meas))
+  unsigned long long* s_rmin_all = reinterpret_cast<unsigned long long*>(s_el + NT);
   const int NXP = P.G + B + kGroup;                              // extended table + one group of padding
-  unsigned long long* s_aux_all = s_rmin_all + (size_t)kWavesPerBlock * NXP;
-  unsigned int* s_walk_all = reinterpret_cast<unsigned int*>(s_aux_all + (size_t)((STAGE || PRODUCT) ? kWavesPerBlock * NXP : 0));
-  float* s_relx = reinterpret_cast<float*>(s_walk_all + (size_t)kWavesPerBlock * kWaveScratch);  // [G + B] extended angle table
+  const int RS = NXP + NE;                                       // per wave: minima per table entry, then (GRID) per entry
+  unsigned long long* s_aux_all = s_rmin_all + (size_t)WPB * RS;
+  unsigned int* s_walk_all = reinterpret_cast<unsigned int*>(s_aux_all + (size_t)((STAGE || PRODUCT) ? WPB * RS : 0));
+  float* s_relx = reinterpret_cast<float*>(s_walk_all + (size_t)WPB * kWaveScratch);  // [G + B] extended angle table
   unsigned short* s_perm = reinterpret_cast<unsigned short*>(s_relx + NXP);
   unsigned short* s_lut = s_perm + B;
+  unsigned short* s_cls = s_lut + NB;                             // [NE] class of entry e (GRID)
 
   for (int k = threadIdx.x; k < B; k += blockDim.x) {
     s_ts[k] = P.tab_sorted[k];
     s_perm[k] = P.perm[k];
-    if (!STAGE) {
-      s_zt[k] = P.zt[k];
-      s_el[k] = P.etalam[k];   // GRID mode: exp(-lambda * z_meas) of the entry
-    }
   }
+  if (!STAGE)
+    for (int k = threadIdx.x; k < NT; k += blockDim.x) {
+      s_zt[k] = P.zt[k];
+      s_el[k] = P.etalam[k];
+    }
+  if (GRID)
+    for (int k = threadIdx.x; k < NE; k += blockDim.x) s_cls[k] = P.g_cls[k];
   for (int k = threadIdx.x; k < NXP; k += blockDim.x) s_relx[k] = (k < P.G + B) ? P.relx[k] : 1.0e30f;  // padding: beyond any window
   for (int k = threadIdx.x; k < NB; k += blockDim.x) s_lut[k] = P.lut[k];
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: particle index, pose and slice bounds live in scalar registers
-  unsigned long long* const rmin = s_rmin_all + (size_t)wv * NXP;  // per extended-table entry: bits of the smallest r2
-  unsigned long long* const aux = s_aux_all + (size_t)wv * NXP;    // STAGE: hit cell per entry; PRODUCT: p_k in caller order
+  unsigned long long* const rmin = s_rmin_all + (size_t)wv * RS;   // per extended-table entry: bits of the smallest r2
+  unsigned long long* const emin = rmin + NXP;                     // GRID: per entry, what only its own angle let in
+  unsigned long long* const aux = s_aux_all + (size_t)wv * RS;     // STAGE: hit cell per entry; PRODUCT: p_k in caller order
   unsigned int* const ring = s_walk_all + (size_t)wv * kWaveScratch;   // [128] cells waiting to be matched
 
   const unsigned long long r2max_bits = (unsigned long long)__double_as_longlong(P.r2max);
@@ -193,8 +205,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? MCL_RAY_WAVES : 4)) void ray
 #ifdef MCL_COUNTS
   unsigned long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
-  int64_t p = (int64_t)blockIdx.x * kWavesPerBlock + wv;
+  const int64_t stride = (int64_t)gridDim.x * WPB;
+  int64_t p = (int64_t)blockIdx.x * WPB + wv;
   T nx = (T)0, ny = (T)0, nth = (T)0;
   unsigned char npm = 0;
   if (p < n) { nx = xs[p]; ny = ys[p]; nth = ths[p]; if (!STAGE && !GRID) npm = pm[p]; }
@@ -202,7 +214,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? MCL_RAY_WAVES : 4)) void ray
     STAMP(7);
     const double x = (double)nx, y = (double)ny, th = (double)nth;
     const bool on_free = npm != 0;
-    for (int k = lane; k < NXP; k += 64) {
+    for (int k = lane; k < RS; k += 64) {
       rmin[k] = r2max_bits;
       if (STAGE) aux[k] = 0xffffffffull;
     }
@@ -303,11 +315,19 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? MCL_RAY_WAVES : 4)) void ray
                 const bool live = (STAGE && phase == 1) ? (rmj == r2bits) : (r2bits < rmj);
                 if (live && ae > sure_in && ae < sure_out) {
                   const int ke = ie - G + (ie < G ? B : 0);   // its beam, sorted order
-                  const double beta = s_ts[ke] + th;          // :143
-                  const double de = fabs(beta - a_exact);     // :148
-                  if ((de <= P.half) || (de >= P.two_pi_lo && de <= P.two_pi_hi)) {  // :149
-                    if (!STAGE || phase == 0) atomicMin(&rmin[ie], r2bits);
-                    else atomicMin(&aux[ie], cellbits);
+                  if constexpr (GRID) {
+                    // every entry of the class with its own angle (robot.py:252-258)
+                    for (int m = P.g_cls_first[ke]; m < P.g_cls_first[ke + 1]; ++m) {
+                      const double de = fabs((P.g_mbeta[m] + th) - a_exact);
+                      if ((de <= P.half) || (de >= P.two_pi_lo && de <= P.two_pi_hi)) atomicMin(&emin[P.g_member[m]], r2bits);
+                    }
+                  } else {
+                    const double beta = s_ts[ke] + th;          // :143
+                    const double de = fabs(beta - a_exact);     // :148
+                    if ((de <= P.half) || (de >= P.two_pi_lo && de <= P.two_pi_hi)) {  // :149
+                      if (!STAGE || phase == 0) atomicMin(&rmin[ie], r2bits);
+                      else atomicMin(&aux[ie], cellbits);
+                    }
                   }
                 }
               }
@@ -393,8 +413,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? MCL_RAY_WAVES : 4)) void ray
       // Histogram filter (robot.py:289-300): the pose is a grid cell, the beam table holds every
       // (heading, beam) pair of that cell, and the measured range is the FIRST argument of
       // compute_px here (range_sensor.py:95-112 called from robot.py:297), the predicted one the second.
-      for (int k = lane; k < B; k += 64) {
-        const double z = sqrt(__longlong_as_double((long long)rmin[G + k]));   // robot.py:269
+      for (int k = lane; k < NE; k += 64) {
+        const unsigned long long mc = rmin[G + s_cls[k]], me = emin[k];
+        const double z = sqrt(__longlong_as_double((long long)(mc < me ? mc : me)));   // robot.py:269
         const double xm = s_zt[k];
         const bool in_range = (0.0 <= xm) && (xm <= P.z_max);
         const double d = xm - z;
@@ -407,14 +428,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? MCL_RAY_WAVES : 4)) void ray
         const double p_max = (fabs(xm - P.z_max) < 1e-6) ? 1.0 : 0.0;
         const double p_rand = in_range ? P.p_rand : 0.0;
         const double pkd = p_hit * P.w_hit + p_short * P.w_short + p_max * P.w_max + p_rand * P.w_rand;
-        rmin[G + k] = (unsigned long long)__double_as_longlong(pkd);   // in place: the minimum of entry k is spent
+        emin[k] = (unsigned long long)__double_as_longlong(pkd);   // in place: the minimum of entry k is spent
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       const int64_t cell = P.g_cell[p];
       for (int d = lane; d < P.g_D; d += 64) {
         double q = 1.0;   // q *= p_k in beam order (robot.py:295-298)
-        for (int k = 0; k < P.g_B0; ++k)
-          q = q * __longlong_as_double((long long)rmin[G + P.g_inv_perm[d * P.g_B0 + k]]);
+        for (int k = 0; k < P.g_B0; ++k) q = q * __longlong_as_double((long long)emin[d * P.g_B0 + k]);
         P.g_pk[cell * P.g_D + d] = (float)(P.g_pk_pred[cell * P.g_D + d] * q);   // robot.py:300, float32 store
       }
     } else {
@@ -515,13 +535,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? MCL_RAY_WAVES : 4)) void ray
 #endif
 }
 
-static size_t ray_lds_bytes(int B, int G, int NB, bool aux) {
+static size_t ray_lds_bytes(int B, int G, int NB, bool aux, int waves = kWavesPerBlock, int NE = 0) {
   const int NXP = B + G + kGroup;
-  size_t s = (size_t)3 * B * sizeof(double);
-  s += (size_t)kWavesPerBlock * NXP * sizeof(unsigned long long) * (aux ? 2 : 1);
-  s += (size_t)kWavesPerBlock * kWaveScratch * sizeof(unsigned int);
+  const int NT = NE ? NE : B;
+  size_t s = (size_t)(B + 2 * NT) * sizeof(double);
+  s += (size_t)waves * (NXP + NE) * sizeof(unsigned long long) * (aux ? 2 : 1);
+  s += (size_t)waves * kWaveScratch * sizeof(unsigned int);
   s += (size_t)NXP * sizeof(float);
-  s += ((size_t)B + NB + 2) * sizeof(unsigned short);
+  s += ((size_t)B + NB + NE + 2) * sizeof(unsigned short);
   return (s + 15) & ~(size_t)15;
 }
 
@@ -531,17 +552,33 @@ int launch_grid_update(mclhip_ctx* c, const double* d_x, const double* d_y, cons
                        int64_t n, int n_dir, int beams_per_dir, const double* pk_pred, float* pk) {
   if (n <= 0) return MCLHIP_OK;
   RayParams P = make_ray_params(c);
-  P.g_inv_perm = c->inv_perm;
   P.g_cell = d_cell; P.g_D = n_dir; P.g_B0 = beams_per_dir; P.g_pk_pred = pk_pred; P.g_pk = pk;
-  const size_t lds = ray_lds_bytes(P.B, P.G, P.NB, false);
-  if (lds > 160 * 1024) return fail(c, MCLHIP_E_LIMIT, "heading x beam table does not fit the kernel's LDS budget");
-  auto kern = raycast_kernel<double, false, false, true>;
-  if (lds > 48 * 1024)
-    MCL_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  int64_t blocks = (n + kWavesPerBlock - 1) / kWavesPerBlock;
-  if (blocks > 256 * 8 * 4) blocks = 256 * 8 * 4;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, c->stream, P, d_x, d_y, d_th,
-                     (const uint8_t*)nullptr, n, (double*)nullptr, (double*)nullptr, (double*)nullptr, (int32_t*)nullptr);
+  P.g_NE = c->gl_NE; P.g_cls = c->gl_cls; P.g_cls_first = c->gl_cls_first; P.g_member = c->gl_member; P.g_mbeta = c->gl_mbeta;
+  P.zt = c->gl_zt; P.etalam = c->gl_el;   // per entry, in entry order
+  // as many waves per block as the LDS holds: 16, 12, 8 or 4
+  const size_t lds_max = 160 * 1024;
+  int waves = 16;
+  while (waves > 4 && ray_lds_bytes(P.B, P.G, P.NB, false, waves, P.g_NE) > lds_max) waves -= 4;
+  const size_t lds = ray_lds_bytes(P.B, P.G, P.NB, false, waves, P.g_NE);
+  if (lds > lds_max) return fail(c, MCLHIP_E_LIMIT, "heading x beam table does not fit the kernel's LDS budget");
+  int64_t blocks = (n + waves - 1) / waves;
+  const int64_t max_blocks = 256 * 8 * 4 * 4 / waves;
+  if (blocks > max_blocks) blocks = max_blocks;
+#define MCL_GRID(W)                                                                                                   \
+  do {                                                                                                                \
+    auto kern = raycast_kernel<double, false, false, true, W>;                                                        \
+    if (lds > 48 * 1024)                                                                                              \
+      MCL_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                     (int)lds));                                                                      \
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, P, d_x, d_y, d_th,                 \
+                       (const uint8_t*)nullptr, n, (double*)nullptr, (double*)nullptr, (double*)nullptr,              \
+                       (int32_t*)nullptr);                                                                            \
+  } while (0)
+  if (waves == 16) MCL_GRID(16);
+  else if (waves == 12) MCL_GRID(12);
+  else if (waves == 8) MCL_GRID(8);
+  else MCL_GRID(4);
+#undef MCL_GRID
   MCL_HIP(c, hipGetLastError());
   return MCLHIP_OK;
 }

@@ -6,18 +6,29 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from slam_amd import _lib, workload as W
 from slam_amd.mc_localization import advance_true_pose
+GRID_MODE = len(sys.argv) > 1 and sys.argv[1] == "grid"     # the histogram filter's update instead of the particle filter's
 M, B = 1 << 20, 180
-grid = W.synthetic_map(4096)
-ctx = _lib.Context(0, _lib.F32)
-ctx.set_map(grid, W.RES, W.RES)
+grid = W.synthetic_map(1024 if GRID_MODE else 4096)
+ctx = _lib.Context(0, _lib.F64 if GRID_MODE else _lib.F32)
 w4 = np.array([0.97, 0.005, 0.020, 0.005]); w4 /= w4.sum()
-ctx.set_sensor(W.beam_angles(B), W.Z_MAX, 0.15, 1.0, w4, 5 * np.pi / 180.0)
-X = W.uniform_particles(grid, M)
-ctx.set_particles(X)
-z = ctx.raycast(advance_true_pose(X[0].copy(), (1.5, 0.0), 0.1), want_hits=False)[0][0]
+if GRID_MODE:
+    ctx.grid_set_map(grid, W.RES, W.RES, 200)
+    ctx.grid_set_sensor([0, 15, 30, 45, 60, 75, 90, 345, 330, 315, 300, 285, 270], 72, 5.0, W.Z_MAX, 0.15, 1.0, w4, 5 * np.pi / 180.0)
+    ctx.grid_init_belief()
+    ctx.grid_predict(1.5, 0.0, 0.1, [0.2, 0.1, 0.2, 0.2, 0.1, 0.1])
+    M = int(np.count_nonzero(grid >= 200))      # one wavefront per free cell
+else:
+    ctx.set_map(grid, W.RES, W.RES)
+    ctx.set_sensor(W.beam_angles(B), W.Z_MAX, 0.15, 1.0, w4, 5 * np.pi / 180.0)
+    X = W.uniform_particles(grid, M)
+    ctx.set_particles(X)
+    z = ctx.raycast(advance_true_pose(X[0].copy(), (1.5, 0.0), 0.1), want_hits=False)[0][0]
 base = [ctx.timing_get(100 + i)[0] for i in range(8)]
 base8 = [ctx.timing_get(108 + i)[0] for i in range(8)]
-ctx.step(1.5, 0.0, 0.1, [4, 2, 4, 4, 4, 2], z, 0.3 / M, None, 7, _lib.W_LOG, wait=True)
+if GRID_MODE:
+    ctx.grid_update(np.array([2.0, 3.1, 5.0, 1.2, 0.8, 4.4, 5.0, 2.2, 2.9, 3.3, 5.0, 1.0, 0.6]))
+else:
+    ctx.step(1.5, 0.0, 0.1, [4, 2, 4, 4, 4, 2], z, 0.3 / M, None, 7, _lib.W_LOG, wait=True)
 now = [ctx.timing_get(100 + i)[0] for i in range(8)]
 d = np.array(now, float) - np.array(base, float)
 names = ["setup", "tile lists+scan", "fetch", "prefilter+ring", "match: geometry/bearing/window", "match: beam groups", "likelihood+store", "loop top (stamp overhead)"]
