@@ -322,25 +322,26 @@ int mclhip_grid_set_sensor(mclhip_ctx* c, const double* angles_deg, int B0, int 
   std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(), [&](uint16_t a, uint16_t b) { return red[a] < red[b]; });
   std::vector<double> centre, mbeta(NE);
-  std::vector<uint16_t> cls(NE), first, member(NE);
+  std::vector<uint32_t> cls(NE);
+  std::vector<uint16_t> first, member(NE);
   for (int m = 0; m < NE; ++m) {
     const int e = order[m];
     if (centre.empty() || red[e] - centre.back() > 1e-9) { centre.push_back(red[e]); first.push_back((uint16_t)m); }
-    cls[e] = (uint16_t)(centre.size() - 1);
+    cls[e] = ((uint32_t)(centre.size() - 1) << 16) | (uint32_t)(e % B0);
     member[m] = (uint16_t)e;
     mbeta[m] = tab[e];
   }
   first.push_back((uint16_t)NE);
   G_TRY(set_sensor_table(c, centre.data(), (int)centre.size(), z_max, sigma_hit, lambda_short, w4, half));
   c->gl_NE = NE;
-  G_TRY(galloc(c, &c->gl_cls, NE * sizeof(uint16_t)));
+  G_TRY(galloc(c, &c->gl_cls, NE * sizeof(uint32_t)));
   G_TRY(galloc(c, &c->gl_cls_first, first.size() * sizeof(uint16_t)));
   G_TRY(galloc(c, &c->gl_member, NE * sizeof(uint16_t)));
   G_TRY(galloc(c, &c->gl_mbeta, NE * sizeof(double)));
-  G_TRY(galloc(c, &c->gl_zt, NE * sizeof(double)));
-  G_TRY(galloc(c, &c->gl_el, NE * sizeof(double)));
+  G_TRY(galloc(c, &c->gl_zt, B0 * sizeof(double)));
+  G_TRY(galloc(c, &c->gl_el, B0 * sizeof(double)));
   G_TRY(galloc(c, &c->gl_zm, B0 * sizeof(double)));
-  MCL_HIP(c, hipMemcpy(c->gl_cls, cls.data(), NE * sizeof(uint16_t), hipMemcpyHostToDevice));
+  MCL_HIP(c, hipMemcpy(c->gl_cls, cls.data(), NE * sizeof(uint32_t), hipMemcpyHostToDevice));
   MCL_HIP(c, hipMemcpy(c->gl_cls_first, first.data(), first.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   MCL_HIP(c, hipMemcpy(c->gl_member, member.data(), NE * sizeof(uint16_t), hipMemcpyHostToDevice));
   MCL_HIP(c, hipMemcpy(c->gl_mbeta, mbeta.data(), NE * sizeof(double), hipMemcpyHostToDevice));
@@ -433,7 +434,7 @@ int mclhip_grid_update(mclhip_ctx* c, const double* z_meas, float* sum_out) {
   MCL_HIP(c, hipMemcpy(c->gl_zm, z_meas, B0 * sizeof(double), hipMemcpyHostToDevice));
   const int64_t n = (int64_t)c->H * c->W * D;
   Timer tm(c, 4);
-  G_TRY(launch_grid_beam_table(c, c->gl_zm, B0, c->gl_NE, c->gl_zt, c->gl_el));
+  G_TRY(launch_grid_beam_table(c, c->gl_zm, B0, B0, c->gl_zt, c->gl_el));
   MCL_HIP(c, hipMemsetAsync(c->gl_pk, 0, n * sizeof(float), c->stream));   // cells below the threshold (robot.py:302)
   G_TRY(launch_grid_update(c, c->gl_x, c->gl_y, c->gl_th, c->gl_cell, c->gl_nfree, D, B0, c->gl_pk_pred, c->gl_pk));
   const int64_t nchunks = (n + kSumChunk - 1) / kSumChunk;

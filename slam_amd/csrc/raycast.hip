@@ -146,20 +146,20 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (sizeo
   const int B = P.B, NB = P.NB;
   // GRID: the beam table holds the classes of (heading, beam) entries that share a bearing; NE entries
   const int NE = GRID ? P.g_NE : 0;
-  const int NT = GRID ? NE : B;                                   // rows of the per-beam mixture tables
+  const int NT = GRID ? P.g_B0 : B;                               // rows of the per-beam mixture tables
   // block-wide tables
   double* s_ts = reinterpret_cast<double*>(smem);                 // [B] sorted beam angles
-  double* s_zt = s_ts + B;                                        // [NT] measured range (sorted order; GRID: entry order)
+  double* s_zt = s_ts + B;                                        // [NT] measured range (sorted order; GRID: per beam of one heading)
   double* s_el = s_zt + NT;                                       // [NT] eta*lambda (GRID: exp(-lambda * z_meas))
   unsigned long long* s_rmin_all = reinterpret_cast<unsigned long long*>(s_el + NT);
   const int NXP = P.G + B + kGroup;                              // extended table + one group of padding
-  const int RS = NXP + NE;                                       // per wave: minima per table entry, then (GRID) per entry
+  const int RS = NXP + NE + (GRID ? B : 0);                      // per wave: minima per table entry, then (GRID) per entry, and a double per class
   unsigned long long* s_aux_all = s_rmin_all + (size_t)WPB * RS;
   unsigned int* s_walk_all = reinterpret_cast<unsigned int*>(s_aux_all + (size_t)((STAGE || PRODUCT) ? WPB * RS : 0));
   float* s_relx = reinterpret_cast<float*>(s_walk_all + (size_t)WPB * kWaveScratch);  // [G + B] extended angle table
   unsigned short* s_perm = reinterpret_cast<unsigned short*>(s_relx + NXP);
   unsigned short* s_lut = s_perm + B;
-  unsigned short* s_cls = s_lut + NB;                             // [NE] class of entry e (GRID)
+  unsigned int* s_cls = reinterpret_cast<unsigned int*>(s_lut + ((NB + B + 1) & ~1) - B);   // [NE] class << 16 | beam of entry e (GRID), 4-byte aligned
 
   for (int k = threadIdx.x; k < B; k += blockDim.x) {
     s_ts[k] = P.tab_sorted[k];
@@ -413,22 +413,64 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (sizeo
       // Histogram filter (robot.py:289-300): the pose is a grid cell, the beam table holds every
       // (heading, beam) pair of that cell, and the measured range is the FIRST argument of
       // compute_px here (range_sensor.py:95-112 called from robot.py:297), the predicted one the second.
-      for (int k = lane; k < NE; k += 64) {
-        const unsigned long long mc = rmin[G + s_cls[k]], me = emin[k];
-        const double z = sqrt(__longlong_as_double((long long)(mc < me ? mc : me)));   // robot.py:269
-        const double xm = s_zt[k];
+      // what depends on the predicted range alone -- the root and the normaliser of the short-reading
+      // term (range_sensor.py:48) -- once per class; an entry that its own angle gave a nearer cell redoes it
+      double* const etac = reinterpret_cast<double*>(emin + NE);
+      for (int cc = lane; cc < B; cc += 64) {
+        const double z = sqrt(__longlong_as_double((long long)rmin[G + cc]));   // robot.py:269
+        etac[cc] = 1.0 / (1.0 - exp(-P.lambda * z));
+        rmin[G + cc] = (unsigned long long)__double_as_longlong(z);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      // p(z_meas | z_pred) of one entry (range_sensor.py:95-112 called from robot.py:297)
+      auto entry_px = [&](int kb, double z, double eta) -> double {
+        const double xm = s_zt[kb];
         const bool in_range = (0.0 <= xm) && (xm <= P.z_max);
         const double d = xm - z;
         const double p_hit = in_range ? P.c_hit * exp(-0.5 * (d * d) / P.sigma2) : 0.0;
-        double p_short = 0.0;
-        if ((0.0 <= xm) && (xm <= z)) {
-          const double eta = 1.0 / (1.0 - exp(-P.lambda * z));
-          p_short = eta * P.lambda * s_el[k];   // exp(-lambda * z_meas), tabulated per entry
-        }
+        const double p_short = ((0.0 <= xm) && (xm <= z)) ? eta * P.lambda * s_el[kb] : 0.0;   // exp(-lambda * z_meas) tabulated per beam
         const double p_max = (fabs(xm - P.z_max) < 1e-6) ? 1.0 : 0.0;
         const double p_rand = in_range ? P.p_rand : 0.0;
-        const double pkd = p_hit * P.w_hit + p_short * P.w_short + p_max * P.w_max + p_rand * P.w_rand;
-        emin[k] = (unsigned long long)__double_as_longlong(pkd);   // in place: the minimum of entry k is spent
+        return p_hit * P.w_hit + p_short * P.w_short + p_max * P.w_max + p_rand * P.w_rand;
+      };
+      // entries whose own minimum may undercut their class wait in the ring and are done together, so the
+      // common case stays free of the root / exponential / division they need
+      auto own_range = [&](unsigned int k) {
+        const unsigned int ck = s_cls[k];
+        const int cc = (int)(ck >> 16);
+        double z = __longlong_as_double((long long)rmin[G + cc]);
+        double eta = etac[cc];
+        const double zo = sqrt(__longlong_as_double((long long)emin[k]));
+        if (zo < z) { z = zo; eta = 1.0 / (1.0 - exp(-P.lambda * z)); }
+        emin[k] = (unsigned long long)__double_as_longlong(entry_px((int)(ck & 0xffffu), z, eta));
+      };
+      int waiting = 0;
+      for (int k0 = 0; k0 < NE; k0 += 64) {
+        const int k = k0 + lane;
+        bool own = false;
+        if (k < NE) {
+          const unsigned int ck = s_cls[k];
+          const int cc = (int)(ck >> 16);
+          const double z = __longlong_as_double((long long)rmin[G + cc]);
+          const unsigned long long me = emin[k];
+          own = (me != r2max_bits) && (__longlong_as_double((long long)me) <= z * z * (1.0 + 1e-15));
+          if (!own) emin[k] = (unsigned long long)__double_as_longlong(entry_px((int)(ck & 0xffffu), z, etac[cc]));   // in place: the minimum is spent
+        }
+        const unsigned long long om = __ballot(own);
+        if (own) {
+          const unsigned int pos = __builtin_amdgcn_mbcnt_hi((unsigned int)(om >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)om, 0u));
+          ring[waiting + (int)pos] = (unsigned int)k;
+        }
+        waiting += __popcll(om);
+        if (waiting >= 64) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          own_range(ring[waiting - 64 + lane]);
+          waiting -= 64;
+        }
+      }
+      if (waiting > 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane < waiting) own_range(ring[lane]);
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       const int64_t cell = P.g_cell[p];
@@ -535,14 +577,15 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (sizeo
 #endif
 }
 
-static size_t ray_lds_bytes(int B, int G, int NB, bool aux, int waves = kWavesPerBlock, int NE = 0) {
+static size_t ray_lds_bytes(int B, int G, int NB, bool aux, int waves = kWavesPerBlock, int NE = 0, int B0 = 0) {
   const int NXP = B + G + kGroup;
-  const int NT = NE ? NE : B;
+  const int NT = NE ? B0 : B;
   size_t s = (size_t)(B + 2 * NT) * sizeof(double);
-  s += (size_t)waves * (NXP + NE) * sizeof(unsigned long long) * (aux ? 2 : 1);
+  s += (size_t)waves * (NXP + NE + (NE ? B : 0)) * sizeof(unsigned long long) * (aux ? 2 : 1);
   s += (size_t)waves * kWaveScratch * sizeof(unsigned int);
   s += (size_t)NXP * sizeof(float);
-  s += ((size_t)B + NB + NE + 2) * sizeof(unsigned short);
+  s += ((size_t)B + NB + 4) * sizeof(unsigned short);
+  s += (size_t)NE * sizeof(unsigned int);
   return (s + 15) & ~(size_t)15;
 }
 
@@ -554,12 +597,12 @@ int launch_grid_update(mclhip_ctx* c, const double* d_x, const double* d_y, cons
   RayParams P = make_ray_params(c);
   P.g_cell = d_cell; P.g_D = n_dir; P.g_B0 = beams_per_dir; P.g_pk_pred = pk_pred; P.g_pk = pk;
   P.g_NE = c->gl_NE; P.g_cls = c->gl_cls; P.g_cls_first = c->gl_cls_first; P.g_member = c->gl_member; P.g_mbeta = c->gl_mbeta;
-  P.zt = c->gl_zt; P.etalam = c->gl_el;   // per entry, in entry order
+  P.zt = c->gl_zt; P.etalam = c->gl_el;   // per beam of one heading
   // as many waves per block as the LDS holds: 16, 12, 8 or 4
   const size_t lds_max = 160 * 1024;
   int waves = 16;
-  while (waves > 4 && ray_lds_bytes(P.B, P.G, P.NB, false, waves, P.g_NE) > lds_max) waves -= 4;
-  const size_t lds = ray_lds_bytes(P.B, P.G, P.NB, false, waves, P.g_NE);
+  while (waves > 4 && ray_lds_bytes(P.B, P.G, P.NB, false, waves, P.g_NE, P.g_B0) > lds_max) waves -= 4;
+  const size_t lds = ray_lds_bytes(P.B, P.G, P.NB, false, waves, P.g_NE, P.g_B0);
   if (lds > lds_max) return fail(c, MCLHIP_E_LIMIT, "heading x beam table does not fit the kernel's LDS budget");
   int64_t blocks = (n + waves - 1) / waves;
   const int64_t max_blocks = 256 * 8 * 4 * 4 / waves;
