@@ -72,24 +72,31 @@ __global__ void grid_coeff_kernel(GridMotion m, int D, int DT, int NC, double* _
   K[idx] = p;
 }
 
-// 16x16 output cells per block, DT headings per thread, neighbour headings staged NC at a time.
-template <int DT, int NC>
+// (16 CX) x 16 output cells per block, CX cells (16 columns apart) and DT headings per thread, neighbour
+// headings staged NC at a time.  The coefficients are uniform over the block and arrive through scalar loads;
+// every one of them feeds CX multiply-adds per lane, which divides the scalar traffic per unit of arithmetic.
+#ifndef GRID_CX
+#define GRID_CX 2
+#endif
+template <int DT, int NC, int CX = GRID_CX>
 __global__ __launch_bounds__(256) void grid_predict_kernel(const float* __restrict__ pk, const double* __restrict__ K,
                                                            const uint8_t* __restrict__ mask, double* __restrict__ out,
                                                            int H, int W, int D) {
-  constexpr int TS = 16, TWD = TS + 2 * kReach;
-  __shared__ float tile[TWD * TWD * NC];
+  constexpr int TSX = 16 * CX, TSY = 16, TWX = TSX + 2 * kReach, TWY = TSY + 2 * kReach;
+  __shared__ float tile[TWX * TWY * NC];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int j0 = blockIdx.x * TS, i0 = blockIdx.y * TS;
+  const int j0 = blockIdx.x * TSX, i0 = blockIdx.y * TSY;
   const int dg = blockIdx.z;
   const int nchunk = D / NC;
-  double acc[DT];
+  double acc[CX][DT];
 #pragma unroll
-  for (int q = 0; q < DT; ++q) acc[q] = 0.0;
+  for (int h = 0; h < CX; ++h)
+#pragma unroll
+    for (int q = 0; q < DT; ++q) acc[h][q] = 0.0;
   for (int ch = 0; ch < nchunk; ++ch) {
     __syncthreads();
-    for (int t = threadIdx.x; t < TWD * TWD * NC; t += 256) {
-      const int n = t % NC, c = (t / NC) % TWD, r = t / (NC * TWD);
+    for (int t = threadIdx.x; t < TWX * TWY * NC; t += 256) {
+      const int n = t % NC, c = (t / NC) % TWX, r = t / (NC * TWX);
       const int gi = i0 + r - kReach, gj = j0 + c - kReach;
       float v = 0.0f;
       if (gi >= 0 && gi < H && gj >= 0 && gj < W) v = pk[((size_t)gi * W + gj) * D + ch * NC + n];
@@ -99,21 +106,31 @@ __global__ __launch_bounds__(256) void grid_predict_kernel(const float* __restri
 #pragma unroll 1
     for (int off = 0; off < kOffsets; ++off) {
       const int a = off / kSide, b = off % kSide;
-      const float* tp = &tile[((ty + a) * TWD + tx + b) * NC];
+      const float* tp = &tile[((ty + a) * TWX + tx + b) * NC];
       const double* Ko = K + (((size_t)dg * kOffsets + off) * nchunk + ch) * (DT * NC);   // uniform over the block
 #pragma unroll
       for (int n = 0; n < NC; ++n) {
-        const double v = (double)tp[n];
+        double v[CX];
 #pragma unroll
-        for (int q = 0; q < DT; ++q) acc[q] = fma(Ko[q * NC + n], v, acc[q]);
+        for (int h = 0; h < CX; ++h) v[h] = (double)tp[h * 16 * NC + n];
+#pragma unroll
+        for (int q = 0; q < DT; ++q) {
+          const double k = Ko[q * NC + n];
+#pragma unroll
+          for (int h = 0; h < CX; ++h) acc[h][q] = fma(k, v[h], acc[h][q]);
+        }
       }
     }
   }
-  const int i = i0 + ty, j = j0 + tx;
-  if (i < H && j < W) {
-    const bool live = i >= kReach && i < H - kReach && j >= kReach && j < W - kReach && (mask[(size_t)i * W + j] & 1);   // robot.py:150-157
+  const int i = i0 + ty;
 #pragma unroll
-    for (int q = 0; q < DT; ++q) out[((size_t)i * W + j) * D + dg * DT + q] = live ? acc[q] : 0.0;
+  for (int h = 0; h < CX; ++h) {
+    const int j = j0 + tx + 16 * h;
+    if (i < H && j < W) {
+      const bool live = i >= kReach && i < H - kReach && j >= kReach && j < W - kReach && (mask[(size_t)i * W + j] & 1);   // robot.py:150-157
+#pragma unroll
+      for (int q = 0; q < DT; ++q) out[((size_t)i * W + j) * D + dg * DT + q] = live ? acc[h][q] : 0.0;
+    }
   }
 }
 
@@ -411,7 +428,7 @@ int mclhip_grid_predict(mclhip_ctx* c, double v, double omega, double dt, const 
   Timer tm(c, 3);
   const int nk = D * kOffsets * D;
   hipLaunchKernelGGL(grid_coeff_kernel, dim3((nk + 255) / 256), dim3(256), 0, c->stream, m, D, DT, DT, c->gl_K);
-  dim3 grid((c->W + 15) / 16, (c->H + 15) / 16, D / DT), block(256);
+  dim3 grid((c->W + 16 * GRID_CX - 1) / (16 * GRID_CX), (c->H + 15) / 16, D / DT), block(256);
   if (DT == 8)
     hipLaunchKernelGGL((grid_predict_kernel<8, 8>), grid, block, 0, c->stream, c->gl_pk, c->gl_K, c->gl_mask, c->gl_pk_pred, c->H, c->W, D);
   else if (DT == 4)
