@@ -133,6 +133,32 @@ def test_more_headings_against_the_oracle(n, n_dir, ut):
     assert np.array_equal(got, want), "%d cells differ" % np.sum(got != want)
 
 
+def test_entry_classes_with_negative_and_irregular_angles():
+    """Beams below zero (their table angle reaches the reference's test one turn low), beams that no other
+    heading shares and beams that coincide across headings only after a full turn: the update on classes of
+    entries equals the oracle's entry-by-entry form.  Angles whose sector would leave (-2pi, 4pi) are refused."""
+    n, n_dir, res_theta = 24, 8, 45
+    grid = _small_map(n, n_dir)
+    angles = [-91.0, -44.0, -3.5, 1.0, 46.0, 91.0, 133.7, 181.0, 226.0, 271.0, 316.0, 359.0, 12.25]
+    ctx = _ctx(grid, n_dir, res_theta, angles)
+    rng = np.random.RandomState(5)
+    pred = rng.rand(n, n, n_dir) ** 2
+    pred[grid < 200] = 0
+    z_meas = [0.61, 1.2, 5.0, 2.35, 0.0, 4.99, 3.3, 0.9, 5.0, 1.75, 2.5, 0.3, 4.2]
+    ii, jj, Z = G.predicted_ranges(grid, n_dir, angles=angles, res_theta=res_theta)
+    want, total, _ = G.update(pred, grid, z_meas, n_dir, angles=angles, Z=Z)
+    ctx.grid_set_prediction(pred)
+    got_total = ctx.grid_update(z_meas)
+    got = ctx.grid_get_belief()[0]
+    assert got_total == total
+    assert np.array_equal(got, want), "%d cells differ" % np.sum(got != want)
+    from slam_amd import _lib as L
+    with pytest.raises(L.MclHipError):
+        _ctx(grid, n_dir, res_theta, [0.0] * 12 + [500.0])      # 500 + 315 degrees: beyond two turns
+    with pytest.raises(L.MclHipError):
+        _ctx(grid, n_dir, res_theta, [0.0] * 12 + [-358.0])     # its sector reaches below -2pi
+
+
 def test_map_without_obstacles_and_all_obstacles():
     grid = np.full((16, 16), 255, np.uint8)
     ctx = _ctx(grid, 4, 90)
