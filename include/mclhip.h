@@ -120,6 +120,15 @@ int mclhip_raycast(mclhip_ctx* ctx, const double* poses_aos, int64_t n, double* 
 int mclhip_motion(mclhip_ctx* ctx, const double* poses_aos, int64_t n, double v, double omega, double dt,
                   const double alpha[6], const int16_t* noise_ints, double* poses_out, double* pm_out);
 
+/* Replaces sample_motion_model_velocity(ut, xt_1, dt) of the chapter-5 script
+ * (05_robot_motion/sample_motion_model_velocity.py:90-108), Table 5.3 as printed:
+ * the arc update divides by w_hat whatever its value (w_hat == 0 gives inf / NaN
+ * poses, as numpy's float64 does) and no map is involved, so the context needs
+ * none.  noise_ints as in mclhip_motion (:73-77 draws them with
+ * random_integers(-1000, 1000, 12)); NULL = no noise.  poses_out [n][3]. */
+int mclhip_motion_book(mclhip_ctx* ctx, const double* poses_aos, int64_t n, double v, double omega, double dt,
+                       const double alpha[6], const int16_t* noise_ints, double* poses_out);
+
 /* Replaces RangeSensor.compute_px(z, z_true) (range_sensor.py:95-112) over n pairs. */
 int mclhip_compute_px(mclhip_ctx* ctx, const double* z, const double* z_true, int64_t n, double* p_out);
 

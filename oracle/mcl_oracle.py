@@ -118,6 +118,35 @@ def motion(X, ut, dt, grid, noise_ints=None, alpha=ALPHA, res_x=RES_X, res_y=RES
     return out, free_cell(out[:, 0], out[:, 1], grid, res_x, res_y)
 
 
+ALPHA_BOOK = (0.2, 0.1, 0.2, 0.2, 0.1, 0.1)   # 05_robot_motion/sample_motion_model_velocity.py:11
+
+
+def motion_book(X, ut, dt, noise_ints=None, alpha=ALPHA_BOOK):
+    """Table 5.3 as the chapter-5 script has it (05_robot_motion/sample_motion_model_velocity.py:90-108):
+    the arc form for every w_hat -- w_hat == 0 divides by zero in float64 (inf / NaN poses) -- and no
+    map.  X [M,3]; noise_ints [M,3,12] or None.  Returns X_new [M,3]."""
+    X = np.asarray(X, np.float64)
+    vt, wt = float(ut[0]), float(ut[1])
+    x, y, th = X[:, 0], X[:, 1], X[:, 2]
+    if noise_ints is not None:
+        c1, c2, c3 = noise_coeffs((vt, wt), alpha)
+        s = sum12(np.asarray(noise_ints))
+        v_hat = vt + c1 * s[:, 0]          # :96-98
+        w_hat = wt + c2 * s[:, 1]
+        g_hat = c3 * s[:, 2]
+    else:
+        v_hat = np.full(len(X), vt)
+        w_hat = np.full(len(X), wt)
+        g_hat = np.zeros(len(X))
+    out = np.zeros_like(X)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        q = v_hat / w_hat
+        out[:, 0] = x - q * np.sin(th) + q * np.sin(th + w_hat * dt)   # :102
+        out[:, 1] = y + q * np.cos(th) - q * np.cos(th + w_hat * dt)   # :103
+        out[:, 2] = th + w_hat * dt + g_hat * dt                       # :104
+    return out
+
+
 def motion_single(xt_1, ut, dt, grid, res_x=RES_X, res_y=RES_Y):
     """Noise-free single-pose update as sample() applies it to the true pose
     (mc_localization.py:223).  Keeps the dtype of xt_1's elements in the

@@ -42,6 +42,8 @@ PROTOTYPES = {
     "mclhip_raycast": (C.c_int, [_ctx_p, _dbl_p, C.c_int64, _dbl_p, _i32_p]),
     "mclhip_motion": (C.c_int, [_ctx_p, _dbl_p, C.c_int64, C.c_double, C.c_double, C.c_double, _dbl_p, _i16_p,
                                 _dbl_p, _dbl_p]),
+    "mclhip_motion_book": (C.c_int, [_ctx_p, _dbl_p, C.c_int64, C.c_double, C.c_double, C.c_double, _dbl_p, _i16_p,
+                                     _dbl_p]),
     "mclhip_compute_px": (C.c_int, [_ctx_p, _dbl_p, _dbl_p, C.c_int64, _dbl_p]),
     "mclhip_sample": (C.c_int, [_ctx_p, C.c_double, C.c_double, C.c_double, _dbl_p, _i16_p, C.c_uint64, _dbl_p]),
     "mclhip_normalise": (C.c_int, [_ctx_p, C.c_int, _dbl_p]),
@@ -222,6 +224,21 @@ class Context:
         self._ck(self.lib.mclhip_motion(self.h, _p(P, _dbl_p), n, float(v), float(omega), float(dt), _p(al, _dbl_p),
                                         _p(nz, _i16_p), _p(out, _dbl_p), _p(pm, _dbl_p)), "mclhip_motion")
         return out, pm
+
+    def motion_book(self, poses, v, omega, dt, alpha, noise_ints=None):
+        """Table 5.3 without the straight-line branch and without a map (mclhip_motion_book)."""
+        P = _f64(poses).reshape(-1, 3)
+        n = len(P)
+        al = _f64(alpha, (6,))
+        nz = None
+        if noise_ints is not None:
+            nz = np.ascontiguousarray(noise_ints, dtype=np.int16)
+            if nz.shape != (n, 3, 12):
+                raise ValueError("noise_ints must be [n,3,12]")
+        out = np.empty((n, 3))
+        self._ck(self.lib.mclhip_motion_book(self.h, _p(P, _dbl_p), n, float(v), float(omega), float(dt),
+                                             _p(al, _dbl_p), _p(nz, _i16_p), _p(out, _dbl_p)), "mclhip_motion_book")
+        return out
 
     def compute_px(self, z, z_true):
         z, zt = np.broadcast_arrays(np.asarray(z, np.float64), np.asarray(z_true, np.float64))

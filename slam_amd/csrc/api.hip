@@ -188,6 +188,7 @@ static MotionParams make_motion_params(const mclhip_ctx* c, double v, double ome
   mp.freeb = c->freeb;
   mp.TW = c->TW; mp.TH = c->TH; mp.W = c->W; mp.H = c->H;
   mp.noise_mode = noise_mode;
+  mp.book = 0;
   mp.seed = seed;
   mp.index0 = c->first_index;
   return mp;
@@ -525,10 +526,10 @@ int mclhip_raycast(mclhip_ctx* c, const double* poses, int64_t n, double* ranges
   return MCLHIP_OK;
 }
 
-int mclhip_motion(mclhip_ctx* c, const double* poses, int64_t n, double v, double omega, double dt,
-                  const double alpha[6], const int16_t* noise_ints, double* poses_out, double* pm_out) {
+static int motion_stage(mclhip_ctx* c, const double* poses, int64_t n, double v, double omega, double dt,
+                        const double alpha[6], const int16_t* noise_ints, double* poses_out, double* pm_out, bool book) {
   MCL_TRY(use(c));
-  MCL_TRY(need(c, true, false, false));
+  if (!book) MCL_TRY(need(c, true, false, false));
   if (!poses || !alpha || !poses_out || n <= 0) return fail(c, MCLHIP_E_ARG, "poses/alpha/poses_out NULL or n <= 0");
   std::vector<double> hx(n), hy(n), ht(n);
   for (int64_t i = 0; i < n; ++i) { hx[i] = poses[3 * i]; hy[i] = poses[3 * i + 1]; ht[i] = poses[3 * i + 2]; }
@@ -548,6 +549,7 @@ int mclhip_motion(mclhip_ctx* c, const double* poses, int64_t n, double v, doubl
     e = hipMemcpyAsync(dn, noise_ints, (size_t)n * 36 * sizeof(int16_t), hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) {
     MotionParams mp = make_motion_params(c, v, omega, dt, alpha, noise_ints ? 1 : 0, 0);
+    mp.book = book ? 1 : 0;
     rc = launch_motion(c, dx, dy, dth, dpm, n, mp, dn, MCLHIP_F64);
   }
   std::vector<uint8_t> hpm(n);
@@ -564,6 +566,16 @@ int mclhip_motion(mclhip_ctx* c, const double* poses, int64_t n, double v, doubl
     if (pm_out) pm_out[i] = hpm[i] ? 1.0 : 0.0;
   }
   return MCLHIP_OK;
+}
+
+int mclhip_motion(mclhip_ctx* c, const double* poses, int64_t n, double v, double omega, double dt,
+                  const double alpha[6], const int16_t* noise_ints, double* poses_out, double* pm_out) {
+  return motion_stage(c, poses, n, v, omega, dt, alpha, noise_ints, poses_out, pm_out, false);
+}
+
+int mclhip_motion_book(mclhip_ctx* c, const double* poses, int64_t n, double v, double omega, double dt,
+                       const double alpha[6], const int16_t* noise_ints, double* poses_out) {
+  return motion_stage(c, poses, n, v, omega, dt, alpha, noise_ints, poses_out, nullptr, true);
 }
 
 int mclhip_compute_px(mclhip_ctx* c, const double* z, const double* z_true, int64_t n, double* p_out) {

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void motion_kernel(T* __restrict__ xs, T* __re
     g_hat = mp.c3 * sum12(k + 24);            // :91
   }
   double nx, ny, nt;
-  if (fabs(w_hat) > 0.0) {  // mc_localization.py:97-100
+  if (mp.book || fabs(w_hat) > 0.0) {  // mc_localization.py:97-100; the book's form divides by w_hat whatever it is
     double q = v_hat / w_hat;
     double wd = w_hat * mp.dt;
     nx = x - q * sin(th) + q * sin(th + wd);
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void motion_kernel(T* __restrict__ xs, T* __re
   xs[i] = sx;
   ys[i] = sy;
   ths[i] = st;
-  pm[i] = on_free_cell((double)sx, (double)sy, mp) ? 1 : 0;
+  pm[i] = (!mp.book && on_free_cell((double)sx, (double)sy, mp)) ? 1 : 0;
 }
 
 // Initial particle cloud drawn on the device (mc_localization.py:173-219): rejection sampling of

@@ -70,6 +70,7 @@ struct MotionParams {
   const uint64_t* freeb; // free-cell bit plane, tiled like the obstacle plane
   int TW, TH, W, H;
   int noise_mode;        // 0 none, 1 pre-drawn integers, 2 device generator
+  int book;              // 1: Table 5.3 as printed (05_robot_motion/sample_motion_model_velocity.py:90-108): no straight-line branch, no map
   uint64_t seed;
   int64_t index0;        // global index of particle 0 (keys the device generator)
 };

@@ -145,3 +145,37 @@ def test_augmented_mcl_stages_bit_exact(name):
         Xo, wo, _ = O.amcl_resample(X, wn, float(s["r"]), s["inj_rows"], s["inj_poses"])
         assert np.array_equal(Xo, s["X_out"])
         assert np.array_equal(wo, s["w_out"])
+
+
+def test_chapter5_motion_sampler_bit_exact():
+    """Table 5.3 without the straight-line branch (05_robot_motion/sample_motion_model_velocity.py:90-108)."""
+    g = load("motion05")
+    al = tuple(g["alpha"])
+    for c, ut in enumerate(g["controls"]):
+        assert np.array_equal(O.motion_book(g["X"], ut, float(g["dt"]), g["noise"][c], al), g["X_out"][c])
+    Z = O.motion_book(g["X"], (1.5, 0.0), float(g["dt"]), np.zeros((len(g["X"]), 3, 12), np.int16), al)
+    assert np.array_equal(Z, g["X_out_zero"], equal_nan=True)
+    assert np.all(np.isnan(Z[:, :2])) and np.all(np.isfinite(Z[:, 2]))   # 1.5 / 0 -> inf - inf
+
+
+def test_chapter4_low_variance_sampler_bit_exact():
+    """ParticleFilter.resample of 04_nonparametric_filters/particle_filter.py:58-81."""
+    g = load("particle_filter04")
+    assert int(g["n_cases"]) == 6
+    for n in range(int(g["n_cases"])):
+        w = g["c%d_w" % n]
+        wn = w / np.sum(w)
+        idx = O.resample_indices(wn, float(g["c%d_r" % n]))
+        assert np.array_equal(g["c%d_X" % n][idx], g["c%d_X_out" % n])
+        assert np.array_equal(wn[idx], g["c%d_w_out" % n])
+
+
+def test_chapter5_density_helper_matches_reference():
+    """Host helper of the drop-in module (Table 5.1); pure numpy, needs no GPU."""
+    from slam_amd import sample_motion_model_velocity as mv
+    g = load("motion05")
+    ut = np.array([10.0, np.pi / 4 * 10])
+    d = np.array([mv.motion_model_velocity(g["dens_xt"][i], ut, g["dens_xt1"][i], dt=float(g["dt"]))
+                  for i in range(len(g["dens"]))])
+    assert np.array_equal(d, g["dens"])
+    assert mv.alpha == list(g["alpha"]) and mv.delta_t == float(g["dt"])

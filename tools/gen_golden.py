@@ -622,9 +622,140 @@ def case_fastslam():
               [r["normals"].shape[1] for r in recs][:8])
 
 
+def _load_script(path, name, shadow=()):
+    """Runs one of the reference's stand-alone scripts as a module (they have no __main__ guard: the
+    demo they contain runs once, headless, output discarded) and returns it.  `shadow`: names of
+    already-imported modules a same-named sibling of the script must replace while it loads."""
+    import importlib.util
+    saved = {k: sys.modules.pop(k) for k in shadow if k in sys.modules}
+    sys.path.insert(0, os.path.dirname(path))
+    try:
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        with contextlib.redirect_stdout(io.StringIO()):
+            spec.loader.exec_module(mod)
+        import matplotlib.pyplot as plt
+        plt.close("all")
+    finally:
+        sys.path.remove(os.path.dirname(path))
+        for k in shadow:
+            sys.modules.pop(k, None)
+        sys.modules.update(saved)
+    return mod
+
+
+def case_particle_filter04():
+    """The low-variance sampler of the chapter-4 script (04_nonparametric_filters/particle_filter.py:58-81):
+    its ParticleFilter.resample() on weight vectors of several sizes, then three iterations of the
+    script's own loop body (sample_gaussian, importance weights, resample) for the drop-in class."""
+    np.random.seed(404)
+    pf = _load_script("/root/reference/04_nonparametric_filters/particle_filter.py", "ref_particle_filter04")
+    out = {}
+    n = 0
+    for seed, M, kind in [(41, 50, "rand"), (42, 50, "peaky"), (43, 777, "zeros"), (44, 2048, "rand"), (45, 64, "equal"),
+                          (46, 1, "rand")]:
+        rng = np.random.RandomState(seed)
+        w = {"rand": rng.rand(M), "peaky": rng.rand(M) ** 30, "zeros": rng.rand(M) * (rng.rand(M) < 0.4),
+             "equal": np.ones(M)}[kind]
+        pf.M = M                                   # the method reads the module's M (:71, :87)
+        obj = pf.ParticleFilter(M, np.ones(pf.x_max) / pf.x_max)
+        X = rng.uniform(0, pf.x_max - 1, M)
+        obj.X = list(X)
+        obj.w = w.copy()
+        np.random.seed(seed)
+        st = np.random.get_state()
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                obj.resample()
+        except IndexError:
+            continue
+        np.random.set_state(st)
+        r = np.random.rand() * 1 / M
+        out["c%d_w" % n] = w
+        out["c%d_X" % n] = X
+        out["c%d_r" % n] = np.float64(r)
+        out["c%d_X_out" % n] = np.array(obj.X, np.float64)
+        out["c%d_w_out" % n] = np.array(obj.w, np.float64)
+        out["c%d_px" % n] = np.array(obj.px, np.float64)
+        n += 1
+    out["n_cases"] = np.array(n)
+    out["x_max"] = np.array(pf.x_max)
+    # the script's loop (:110-162) without the plotting, three iterations
+    M = 50
+    pf.M = M
+    np.random.seed(7)
+    flt = pf.ParticleFilter(M, np.ones(pf.x_max) / pf.x_max)
+    for it in range(3):
+        with contextlib.redirect_stdout(io.StringIO()):
+            if it == 0:
+                flt.sample_uniform()
+            else:
+                flt.sample_gaussian()
+            pz = np.zeros([pf.x_max])
+            for m in range(M):
+                z = int(np.clip(flt.X[m], a_min=0, a_max=pf.x_max - 1) + 0.5)
+                pz[z] += 1
+            pz /= M
+            for m in range(M):
+                z = int(np.clip(flt.X[m], a_min=0, a_max=pf.x_max - 1) + 0.5)
+                flt.w[m] = pf.normal_dist(pf.x_obj, 1, z) * pz[z] / (flt.px[z] + 1e-6)
+            out["loop%d_X_in" % it] = np.array(flt.X, np.float64)
+            out["loop%d_w_in" % it] = np.array(flt.w, np.float64)
+            flt.resample()
+        out["loop%d_X" % it] = np.array(flt.X, np.float64)
+        out["loop%d_w" % it] = np.array(flt.w, np.float64)
+        out["loop%d_px" % it] = np.array(flt.px, np.float64)
+    out["x_obj"] = np.array(pf.x_obj)
+    np.savez_compressed(os.path.join(OUT, "particle_filter04.npz"), **out)
+    print("wrote particle_filter04", n)
+
+
+def case_motion05():
+    """Table 5.3 as the chapter-5 script states it (05_robot_motion/sample_motion_model_velocity.py:90-108;
+    no straight-line branch, alpha of :11): its sample_motion_model_velocity over many poses and
+    controls with the integers it drew, and with the sampler forced to zero at w = 0 (division by zero)."""
+    np.random.seed(505)
+    mv = _load_script("/root/reference/05_robot_motion/sample_motion_model_velocity.py", "ref_motion05",
+                      shadow=("robot",))
+    rng = np.random.RandomState(6)
+    N = 1500
+    X = np.stack([rng.uniform(-3, 12, N), rng.uniform(-3, 12, N), rng.uniform(-7, 7, N)], 1)
+    ctrls = [(10.0, np.pi / 4 * 10), (1.5, 0.5), (1.5, 0.0), (-0.7, -1.2), (0.0, 0.9)]
+    np.random.seed(98)
+    st = np.random.get_state()
+    Xo = np.zeros((len(ctrls), N, 3))
+    for c, ut in enumerate(ctrls):
+        for m in range(N):
+            Xo[c, m] = mv.sample_motion_model_velocity(np.array(ut), X[m], dt=mv.delta_t)
+    np.random.set_state(st)
+    noise = np.random.random_integers(-1000, 1000, size=(len(ctrls), N, 3, 12)).astype(np.int16)
+    Z = np.zeros((N, 3))
+    saved = mv.sample
+    mv.sample = lambda b: np.float64(0.0) * b
+    try:
+        for m in range(N):
+            Z[m] = mv.sample_motion_model_velocity(np.array([1.5, 0.0]), X[m], dt=mv.delta_t)
+    finally:
+        mv.sample = saved
+    # the Table 5.1 density on a few triples (host helper of the drop-in module)
+    T = 64
+    xt = np.stack([rng.uniform(0, 3, T), rng.uniform(0, 3, T), rng.uniform(-3, 3, T)], 1)
+    xt1 = np.stack([rng.uniform(0, 3, T), rng.uniform(0, 3, T), rng.uniform(-3, 3, T)], 1)
+    dens = np.array([mv.motion_model_velocity(xt[i], np.array([10.0, np.pi / 4 * 10]), xt1[i], dt=mv.delta_t) for i in range(T)])
+    np.savez_compressed(os.path.join(OUT, "motion05.npz"), X=X, controls=np.array(ctrls), noise=noise, X_out=Xo,
+                        X_out_zero=Z, alpha=np.array(mv.alpha, np.float64), dt=np.array(mv.delta_t),
+                        dens_xt=xt, dens_xt1=xt1, dens=dens)
+    print("wrote motion05, NaN/inf rows with w_hat == 0:", int(np.sum(~np.isfinite(Z).all(1))))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["demo", "robot", "px", "resample", "motion", "synth", "amcl", "grid", "fastslam"]
+    which = sys.argv[1:] or ["demo", "robot", "px", "resample", "motion", "synth", "amcl", "grid", "fastslam", "pf04",
+                             "motion05"]
+    if "pf04" in which:
+        case_particle_filter04()
+    if "motion05" in which:
+        case_motion05()
     if "amcl" in which:
         case_amcl()
     if "grid" in which:
