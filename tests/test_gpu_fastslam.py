@@ -128,3 +128,38 @@ def test_dropin_class_follows_reference_run():
     assert len(Y) == slam.M and len(Y[0].x) == len(steps(g)) + 1
     assert [len(y.feature) for y in Y] == list(s["nfeat"])
     assert Y[5].feature[0].m.shape == (2, 1) and Y[5].feature[0].Cov.shape == (2, 2)
+
+
+def test_two_measurements_that_pick_the_same_feature():
+    """Landmarks in tight pairs: both measurements of a pair often associate with one feature, which
+    is then updated twice in one step -- the second time with the first update's mean and covariance
+    but the step's original prediction (fast_slam1.py:348-375 reads z_pred, H, invQ of :259-282)."""
+    from slam_amd import _lib as L
+    M, cap = 96, 24
+    base = np.array([[4.0, 1.0], [6.0, -2.0], [3.0, -3.0], [7.0, 2.5]])
+    lm = np.concatenate([base, base + [0.25, 0.1], base[:2] + [-0.1, 0.3]])
+    lm = np.concatenate([lm, np.zeros((len(lm), 1))], 1).astype(np.float32)
+    ctx = L.Context(0, L.F64)
+    ctx.fs_init(M, cap)
+    orc = F.OracleFastSLAM(M, lm)
+    rng = np.random.RandomState(21)
+    x_gt = [0, 0, 0]
+    doubles = 0
+    prev_i = None
+    for t in range(8):
+        ut = [8.0, 0.3] if t % 3 else [8.0, -0.4]
+        x_gt = F.true_pose_step(x_gt, ut)
+        tr, tp, tv = _truth(x_gt, lm)
+        nv = int(tv.sum())
+        ints = rng.randint(-1000, 1000, size=(M, 3, 12)).astype(np.int16)
+        normals = rng.randn(M, 2 * nv)
+        ru = float(rng.rand())
+        idx = ctx.fs_step(ut[0], ut[1], F.DT, F.ALPHA, tr, tp, tv, ints, normals, ru / M, want_idx=True)
+        orc.step(ut, ints, normals, ru)
+        assert np.array_equal(idx, orc.last_idx), t
+        s = orc.state(cap)
+        _compare(ctx.fs_get_state(), s, t)
+        if prev_i is not None:
+            doubles += int(np.sum(s["f_i"] - prev_i[idx] >= 2))
+        prev_i = s["f_i"]
+    assert doubles > 20, doubles     # the case this test is about did occur
