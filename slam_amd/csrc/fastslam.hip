@@ -1,11 +1,14 @@
 // FastSLAM 1.0 with unknown correspondence -- the reference's 13_fast_slam/fast_slam1.py
 // (fast_slam(), :240-433) on the GPU.
 //
-// One thread per particle, three kernels per filter step: pose sample (Table 5.3 with the twelve-integer
-// normal sampler, :160-189) and per-feature measurement prediction / Jacobian / innovation covariance
-// (:259-282); measurement draws, maximum-likelihood association of every sensed landmark with a 2-sigma
-// Mahalanobis gate (:286-315) and feature birth (:318-347) or EKF update (:348-375); the weight /
-// feature-decay pass that removes from the list it iterates (:377-404).  Resampling reuses the
+// One thread per particle, five kernels per filter step: pose sample (Table 5.3 with the twelve-integer
+// normal sampler, :160-189); measurement draws; maximum-likelihood association of every sensed landmark
+// with a 2-sigma Mahalanobis gate (:286-315); feature birth (:318-347) or EKF update (:348-375); the weight /
+// feature-decay pass that removes from the list it iterates (:377-404).  The per-feature measurement
+// prediction / Jacobian / innovation covariance of :259-282 is never stored: it is a function of the
+// feature as it stood before the step and of the sampled pose, so the association sweep and the update
+// each form it from the 48 bytes of the feature they read anyway (same expressions, same results), which
+// spares a 96-byte record per feature slot written and read back every step.  Resampling reuses the
 // order-exact sequential sum / CDF of the particle filter (weights.hip), then one kernel gathers the
 // feature slots of the drawn ancestors.
 //
@@ -19,7 +22,9 @@
 // either pre-drawn standard normals (stream parity) or a seed (device generator).
 //
 // Compiled with -ffp-contract=off.
+#include <algorithm>
 #include <cmath>
+#include <numeric>
 #include <cstring>
 #include <vector>
 
@@ -30,8 +35,12 @@ namespace mcl {
 
 // fields of a feature slot (64-bit words; the last holds the two 32-bit counters)
 enum { F_M0 = 0, F_M1, F_C00, F_C01, F_C10, F_C11, F_W, F_INT, F_WORDS };
-// per-step prediction of a slot: z_pred, H, inv Q, det Q, "seen this step"
-enum { S_ZR = 0, S_ZPHI, S_H00, S_H01, S_H10, S_H11, S_Q00, S_Q01, S_Q10, S_Q11, S_DET, S_UPD, S_WORDS };
+// "updated or created this step" (Feature.updated, :49, :280, :343, :373) is bit 31 of the id half of
+// F_INT, i.e. the sign bit of the 64-bit word: set by the update / birth, read by the decay pass, cleared
+// when the slot is copied to its descendant (gather / exchange rows); ids stay below 2^31
+constexpr int kSectors = 64;   // bearing sectors of the association sweep's landmark index (a power of two)
+constexpr int32_t kUpdBit = (int32_t)0x80000000;
+constexpr long long kUpdMask64 = 0x7fffffffffffffffll;
 // per-step measurement: (r, phi), best likelihood, best feature (-1 none, -2 out of range)
 enum { M_ZR = 0, M_ZPHI, M_BW, M_BC, M_WORDS };
 
@@ -49,9 +58,10 @@ struct FsParams {
   double *x, *y, *th, *wout;
   int32_t *nfeat, *new_id;
   double* feat;             // tiles x F x F_WORDS x 64
-  double* scr;              // tiles x F x S_WORDS x 64
   double* meas;             // tiles x mcap x M_WORDS x 64
   double* noise;            // [2][M]: largest range / bearing noise a particle drew this step
+  double far_r;             // largest noise-free range among the landmarks in range
+  const unsigned long long* sectors;   // [blocks of 64 landmarks][kSectors] which landmarks' bearings lie in a sector; then one mask of all per block
   int32_t* overflow;
 };
 
@@ -60,10 +70,9 @@ struct FsParams {
 __device__ __host__ inline int64_t tile_word(int64_t p, int64_t rows, int64_t row, int words) {
   return ((((p >> 6) * rows + row) * words) << 6) + ((p & 63) << 1);
 }
-#define FREC(slot) (P.feat + tile_word(p, P.F, (slot), F_WORDS))
-#define SREC(slot) (P.scr + tile_word(p, P.F, (slot), S_WORDS))
-#define MREC(u) (P.meas + tile_word(p, P.mcap, (u), M_WORDS))
 #define FLD(rec, f) (rec)[((f) >> 1) * 128 + ((f) & 1)]
+#define FREC(slot) (P.feat + tile_word(p, P.F, (slot), F_WORDS))
+#define MREC(u) (P.meas + tile_word(p, P.mcap, (u), M_WORDS))
 #define FLD_I(rec, f, half) ((int32_t*)&FLD(rec, f))[half]   // 32-bit halves of a word
 
 struct M2 { double a, b, c, d; };   // [[a, b], [c, d]]
@@ -125,11 +134,11 @@ __device__ inline void device_normal_pair(uint64_t particle, uint32_t draw, uint
 #define FS_WAVES 3
 #endif
 #ifndef FS_BATCH
-#define FS_BATCH 6
+#define FS_BATCH 3
 #endif
 
-// ---- pose sample (:160-189) and per-feature prediction (:259-282) ----
-__global__ __launch_bounds__(128) void fs_predict_kernel(const FsParams P) {
+// ---- pose sample (:160-189) ----
+__global__ __launch_bounds__(128) void fs_pose_kernel(const FsParams P) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P.M) return;
   int k[36];
@@ -152,29 +161,30 @@ __global__ __launch_bounds__(128) void fs_predict_kernel(const FsParams P) {
   const double g_hat = P.c3 * sum12(k + 24);
   const double x0 = P.x[p], y0 = P.y[p], th0 = P.th[p];
   const double q = v_hat / w_hat;
-  const double x = x0 - q * sin(th0) + q * sin(th0 + w_hat * P.dt);
-  const double y = y0 + q * cos(th0) - q * cos(th0 + w_hat * P.dt);
-  const double th = th0 + w_hat * P.dt + g_hat * P.dt;
-  P.x[p] = x; P.y[p] = y; P.th[p] = th;
+  P.x[p] = x0 - q * sin(th0) + q * sin(th0 + w_hat * P.dt);
+  P.y[p] = y0 + q * cos(th0) - q * cos(th0 + w_hat * P.dt);
+  P.th[p] = th0 + w_hat * P.dt + g_hat * P.dt;
+}
 
-  const int n_old = P.nfeat[p];
-  for (int j = 0; j < n_old; ++j) {
-    const double* f = FREC(j);
-    double* sc = SREC(j);
-    double r, phi;
-    M2 H;
-    predict_measurement(FLD(f, F_M0), FLD(f, F_M1), x, y, th, &r, &phi, &H);
-    const M2 C{FLD(f, F_C00), FLD(f, F_C01), FLD(f, F_C10), FLD(f, F_C11)};
-    M2 Q = mul(mul(H, C), tr(H));              // :276
-    Q.a = Q.a + P.qt_r; Q.b = Q.b + 0.0; Q.c = Q.c + 0.0; Q.d = Q.d + P.qt_phi;
-    double det;
-    const M2 iq = inv_lu(Q, &det);
-    FLD(sc, S_ZR) = r; FLD(sc, S_ZPHI) = phi;
-    FLD(sc, S_H00) = H.a; FLD(sc, S_H01) = H.b; FLD(sc, S_H10) = H.c; FLD(sc, S_H11) = H.d;
-    FLD(sc, S_Q00) = iq.a; FLD(sc, S_Q01) = iq.b; FLD(sc, S_Q10) = iq.c; FLD(sc, S_Q11) = iq.d;
-    FLD(sc, S_DET) = det;
-    FLD_I(sc, S_UPD, 0) = 0;
-  }
+// ---- per-feature prediction (:259-282): z_pred, H, inv Q, det Q from the feature as it stands before
+// the step's updates and the sampled pose ----
+struct RawFeat { double m0, m1, c00, c01, c10, c11; };
+__device__ inline RawFeat load_raw(const double* f) {
+  return RawFeat{FLD(f, F_M0), FLD(f, F_M1), FLD(f, F_C00), FLD(f, F_C01), FLD(f, F_C10), FLD(f, F_C11)};
+}
+struct Predicted { double fr, fphi, q00, q01, q10, q11, dq; };
+__device__ inline Predicted predict_feature(const RawFeat& r, double x, double y, double th, double qt_r, double qt_phi,
+                                            M2* H_out) {
+  double zr, zphi;
+  M2 H;
+  predict_measurement(r.m0, r.m1, x, y, th, &zr, &zphi, &H);
+  const M2 C{r.c00, r.c01, r.c10, r.c11};
+  M2 Q = mul(mul(H, C), tr(H));              // :276
+  Q.a = Q.a + qt_r; Q.b = Q.b + 0.0; Q.c = Q.c + 0.0; Q.d = Q.d + qt_phi;
+  double det;
+  const M2 iq = inv_lu(Q, &det);
+  if (H_out) *H_out = H;
+  return Predicted{zr, zphi, iq.a, iq.b, iq.c, iq.d, det};
 }
 
 // The out-of-line helpers below see plain values and this lane's record pointers only -- nothing they
@@ -187,7 +197,7 @@ __device__ __attribute__((noinline)) double gate_weight(double d2, double dq) {
 }
 
 // new feature (:318-347)
-__device__ __attribute__((noinline)) void create_feature(double* f, double* sc, int32_t id, double zr, double zphi, double x,
+__device__ __attribute__((noinline)) void create_feature(double* f, int32_t id, double zr, double zphi, double x,
                                                          double y, double th, double qt_r, double qt_phi, double p0) {
   const double m0 = zr * cos(zphi + th) + x, m1 = zr * sin(zphi + th) + y;   // :201-202
   double r_, phi_;
@@ -199,18 +209,17 @@ __device__ __attribute__((noinline)) void create_feature(double* f, double* sc, 
   FLD(f, F_M0) = m0; FLD(f, F_M1) = m1;
   FLD(f, F_C00) = C.a; FLD(f, F_C01) = C.b; FLD(f, F_C10) = C.c; FLD(f, F_C11) = C.d;
   FLD(f, F_W) = p0;
-  FLD_I(f, F_INT, 0) = 1; FLD_I(f, F_INT, 1) = id;
-  FLD_I(sc, S_UPD, 0) = 1;
+  FLD_I(f, F_INT, 0) = 1; FLD_I(f, F_INT, 1) = id | kUpdBit;
 }
 
 // ---- every landmark: draw the measurement, associate, create or update (:286-375) ----
-// The association of a measurement reads only what the prediction pass stored (z_pred, invQ, det Q of the
-// features that existed before this step), never what an earlier measurement of the same step changed.  So
-// all measurements of the step are drawn first and parked in device memory (fs_draw_kernel), ONE sweep
-// over the stored features associates them all (fs_associate_kernel), and then they are applied
-// (fs_apply_kernel): updates in landmark order -- two measurements may pick the same feature -- and
-// births in landmark order; an update touches a feature that existed before the step, a birth a new
-// slot, so the two do not meet.
+// The association of a measurement reads only the prediction of the features that existed before this
+// step, never what an earlier measurement of the same step changed.  So all measurements of the step are
+// drawn first and parked in device memory (fs_draw_kernel), ONE sweep over the stored features associates
+// them all (fs_associate_kernel), and then they are applied (fs_apply_kernel): updates feature by feature
+// -- two measurements may pick the same feature: they are applied one after the other, in landmark order,
+// with the one prediction -- and births in landmark order; an update touches a feature that existed
+// before the step, a birth a new slot, so the two do not meet.
 //
 // A wavefront's time goes into waiting for memory, so each kernel is arranged to have few dependent round
 // trips: loads a step ahead of their use, stores that nothing waits for, out-of-line calls (which drain
@@ -251,149 +260,247 @@ __global__ __launch_bounds__(128) void fs_draw_kernel(const FsParams P, const do
 // The sweep looks at a (feature, measurement) pair closely only if it can pass the gate at all.  For a
 // positive definite Q, r' invQ r >= r_k^2 / Q_kk: each residual alone must be within the gate of its own
 // variance (Q_00 = invQ_11 det Q, Q_11 = invQ_00 det Q).  A measurement differs from the landmark's
-// noise-free reading -- the same for every particle, so it sits in scalar registers -- by at most the
-// largest noise this particle drew, and the angular residual is at least the distance on the circle.  The
-// test uses twice the gate, far beyond any rounding of the quantities involved; neighbouring particles
-// share ancestors and hence feature order, so whole wavefronts skip nearly all pairs.  Eight landmarks are
-// tested per round without a branch; the candidates of a feature are then read together.
-struct Predicted { double fr, fphi, q00, q01, q10, q11, dq; };
-__device__ inline Predicted load_predicted(const double* sc) {
-  return Predicted{FLD(sc, S_ZR), FLD(sc, S_ZPHI), FLD(sc, S_Q00), FLD(sc, S_Q01), FLD(sc, S_Q10), FLD(sc, S_Q11), FLD(sc, S_DET)};
-}
-
+// noise-free reading -- the same for every particle -- by at most the largest noise this particle drew,
+// and the angular residual is at least the distance on the circle.  The test uses twice the gate, far
+// beyond any rounding of the quantities involved.  Of the landmarks only those are tested whose noise-free
+// bearing lies in a sector the feature's window touches: the host files the landmarks of a step by
+// bearing sector (one 64-bit set per sector and block of 64 landmarks), a lane joins the sets of its
+// window and walks the few bits.  The table and the sets are staged in LDS; the candidates of a feature
+// are then read together.
 __global__ __launch_bounds__(128, FS_WAVES) void fs_associate_kernel(const FsParams P, const double2* __restrict__ truth) {
+  extern __shared__ __align__(16) unsigned char fs_assoc_lds[];
+  const int nv = P.L;
+  const int nv8 = (nv + 7) & ~7;                // the table is padded to a multiple of eight with far-away readings
+  const int nblk = (nv + 63) >> 6;
+  double2* const s_truth = reinterpret_cast<double2*>(fs_assoc_lds);                       // [nv8]
+  unsigned long long* const s_sect = reinterpret_cast<unsigned long long*>(s_truth + nv8);  // [nblk][kSectors] + [nblk]
+  for (int k = threadIdx.x; k < nv8; k += blockDim.x) s_truth[k] = truth[k];
+  for (int k = threadIdx.x; k < nblk * (kSectors + 1); k += blockDim.x) s_sect[k] = P.sectors[k];
+  __syncthreads();
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P.M) return;
-  const int nv = P.L;
   const int n_old = P.nfeat[p];
   if (n_old == 0) return;
+  const double x = P.x[p], y = P.y[p], th = P.th[p];
   const double mr = P.noise[p], mphi = P.noise[P.M + p];
   const double two_gate = 2.0 * P.gate2;
+  const double inv_sector = (double)kSectors / (2.0 * M_PI);
   constexpr int kBatch = FS_BATCH;
-  const int nv8 = (nv + 7) & ~7;                // the table is padded to a multiple of eight with far-away readings
-  Predicted next = load_predicted(SREC(0));
+  RawFeat next = load_raw(FREC(0));
   for (int j = 0; j < n_old; ++j) {
-    const Predicted f = next;
-    if (j + 1 < n_old) next = load_predicted(SREC(j + 1));   // in flight during this feature's tests
+    const RawFeat raw = next;
+    if (j + 1 < n_old) next = load_raw(FREC(j + 1));   // in flight during this feature's prediction and tests
+    {
+      // no reading can pass the range gate of a feature that lies further out than the farthest landmark in
+      // range + this particle's largest range noise + the gate of the largest range variance the feature can
+      // have (|h' C h| <= sum |C_ij| for a unit h): such a feature needs no prediction at all
+      const double dx = raw.m0 - x, dy = raw.m1 - y;
+      const double q_cap = (fabs(raw.c00) + fabs(raw.c01)) + (fabs(raw.c10) + fabs(raw.c11)) + P.qt_r;
+      if (sqrt(dx * dx + dy * dy) - (P.far_r + mr) > sqrt(two_gate * q_cap) + 1e-9) continue;
+    }
+    const Predicted f = predict_feature(raw, x, y, th, P.qt_r, P.qt_phi, nullptr);
     const double lim0 = two_gate * (f.q11 * f.dq), lim1 = two_gate * (f.q00 * f.dq);
-    unsigned long long cand = 0;                // measurements that may pass this feature's gate
-    for (int u0 = 0; u0 < nv8; u0 += 8) {
-      unsigned pass = 0;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const double2 t = truth[u0 + k];
+    // a reading can pass only if its noise-free bearing is within `reach` of the predicted one on the circle
+    const double reach = mphi + sqrt(lim1) + 1e-6;
+    const bool everything = !(fabs(f.fphi) < 1.0e6) || !(reach < 3.0);   // also NaN
+    const int b_lo = everything ? 0 : (int)floor((f.fphi - reach + M_PI) * inv_sector);
+    const int b_hi = everything ? -1 : (int)floor((f.fphi + reach + M_PI) * inv_sector);
+    for (int blk = 0; blk < nblk; ++blk) {
+      const int base = blk << 6;
+      unsigned long long look = everything ? s_sect[nblk * kSectors + blk] : 0ull;
+      for (int b = b_lo; b <= b_hi; ++b) look |= s_sect[blk * kSectors + (b & (kSectors - 1))];
+      unsigned long long cand = 0;                // measurements that may pass this feature's gate
+      while (look) {
+        const int k = __ffsll((long long)look) - 1;
+        look &= look - 1;
+        const double2 t = s_truth[base + k];
         const double g0 = fmax(fabs(t.x - f.fr) - mr, 0.0);
         const double d = t.y - f.fphi;
         const double g1 = fmax(fabs(d - (2.0 * M_PI) * rint(d * (0.5 / M_PI))) - mphi, 0.0);
         const bool out = (g0 * g0 > lim0) || (g1 * g1 > lim1);
-        pass |= (out || u0 + k >= nv) ? 0u : (1u << k);
+        if (!out) cand |= 1ull << k;
       }
-      cand |= (unsigned long long)pass << (u0 & 63);
-      if ((u0 & 63) == 56 || u0 + 8 >= nv8) {   // 64 measurements tested: look at the candidates
-        const int base = u0 & ~63;
-        while (cand) {
-          int uu[kBatch];
-          double bw[kBatch], zr[kBatch], zp[kBatch], wj[kBatch];
+      while (cand) {
+        int uu[kBatch];
+        double bw[kBatch], zr[kBatch], zp[kBatch], wj[kBatch];
 #pragma unroll
-          for (int k = 0; k < kBatch; ++k) {
-            uu[k] = -1;
-            if (cand) {
-              uu[k] = base + __ffsll((long long)cand) - 1;
-              cand &= cand - 1;
-              const double* m = MREC(uu[k]);
-              bw[k] = FLD(m, M_BW); zr[k] = FLD(m, M_ZR); zp[k] = FLD(m, M_ZPHI);
+        for (int k = 0; k < kBatch; ++k) {
+          uu[k] = -1;
+          if (cand) {
+            uu[k] = base + __ffsll((long long)cand) - 1;
+            cand &= cand - 1;
+            const double* m = MREC(uu[k]);
+            bw[k] = FLD(m, M_BW); zr[k] = FLD(m, M_ZR); zp[k] = FLD(m, M_ZPHI);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+          wj[k] = -1.0;
+          if (uu[k] >= 0) {
+            const double e0 = zr[k] - f.fr;
+            const double e1 = wrap_residual(zp[k] - f.fphi);
+            const double t0 = e0 * f.q00 + e1 * f.q10;   // r.T @ invQ
+            const double t1 = e0 * f.q01 + e1 * f.q11;
+            const double d2 = t0 * e0 + t1 * e1;
+            if (d2 <= P.gate2) {                          // :307
+              const double w = gate_weight(d2, f.dq);
+              if (bw[k] < w) wj[k] = w;                   // :311 (a NaN likelihood never wins)
             }
           }
+        }
 #pragma unroll
-          for (int k = 0; k < kBatch; ++k) {
-            wj[k] = -1.0;
-            if (uu[k] >= 0) {
-              const double e0 = zr[k] - f.fr;
-              const double e1 = wrap_residual(zp[k] - f.fphi);
-              const double t0 = e0 * f.q00 + e1 * f.q10;   // r.T @ invQ
-              const double t1 = e0 * f.q01 + e1 * f.q11;
-              const double d2 = t0 * e0 + t1 * e1;
-              if (d2 <= P.gate2) {                          // :307
-                const double w = gate_weight(d2, f.dq);
-                if (bw[k] < w) wj[k] = w;                   // :311 (a NaN likelihood never wins)
-              }
-            }
-          }
-#pragma unroll
-          for (int k = 0; k < kBatch; ++k) {
-            if (wj[k] >= 0.0) { double* m = MREC(uu[k]); FLD(m, M_BW) = wj[k]; FLD_I(m, M_BC, 0) = j; }
-          }
+        for (int k = 0; k < kBatch; ++k) {
+          if (wj[k] >= 0.0) { double* m = MREC(uu[k]); FLD(m, M_BW) = wj[k]; FLD_I(m, M_BC, 0) = j; }
         }
       }
     }
   }
 }
 
-// what an EKF update reads of its feature
-struct SlotData { M2 H, iq, C; double zr, zphi, m0, m1, det; int cnt, id; };
-__device__ inline SlotData load_slot(const double* f, const double* sc) {
-  SlotData d;
-  d.H = M2{FLD(sc, S_H00), FLD(sc, S_H01), FLD(sc, S_H10), FLD(sc, S_H11)};
-  d.iq = M2{FLD(sc, S_Q00), FLD(sc, S_Q01), FLD(sc, S_Q10), FLD(sc, S_Q11)};
-  d.C = M2{FLD(f, F_C00), FLD(f, F_C01), FLD(f, F_C10), FLD(f, F_C11)};
-  d.zr = FLD(sc, S_ZR); d.zphi = FLD(sc, S_ZPHI);
+// a feature slot in registers
+struct Slot { double m0, m1; M2 C; double w; int cnt, id; };
+__device__ inline Slot load_slot(const double* f) {
+  Slot d;
   d.m0 = FLD(f, F_M0); d.m1 = FLD(f, F_M1);
+  d.C = M2{FLD(f, F_C00), FLD(f, F_C01), FLD(f, F_C10), FLD(f, F_C11)};
+  d.w = FLD(f, F_W);
   d.cnt = FLD_I(f, F_INT, 0); d.id = FLD_I(f, F_INT, 1);
-  d.det = FLD(sc, S_DET);
   return d;
 }
-struct MeasRec { int c; double zr, zphi, bw; };
-__device__ inline MeasRec load_meas(const double* m) {
-  return MeasRec{FLD_I(m, M_BC, 0), FLD(m, M_ZR), FLD(m, M_ZPHI), FLD(m, M_BW)};
+__device__ inline void store_slot(double* f, const Slot& d) {   // whole 16-byte pairs: no partial lines
+  FLD(f, F_M0) = d.m0; FLD(f, F_M1) = d.m1;
+  FLD(f, F_C00) = d.C.a; FLD(f, F_C01) = d.C.b; FLD(f, F_C10) = d.C.c; FLD(f, F_C11) = d.C.d;
+  FLD(f, F_W) = d.w;
+  FLD_I(f, F_INT, 0) = d.cnt; FLD_I(f, F_INT, 1) = d.id;
 }
 
-// EKF update with the prediction-pass H, invQ, z_pred (:348-375)
-__device__ inline void update_feature(double* f, double* sc, const SlotData& d, double zr, double zphi, double w_max) {
-  const M2 K = mul(mul(d.C, tr(d.H)), d.iq);   // :360
-  const double e0 = zr - d.zr;
-  const double e1 = wrap_residual(zphi - d.zphi);
-  FLD(f, F_M0) = d.m0 + (K.a * e0 + K.b * e1);   // :369
-  FLD(f, F_M1) = d.m1 + (K.c * e0 + K.d * e1);
-  const M2 KH = mul(K, d.H);
+// EKF update (:348-375) with the step's prediction pr / H of the feature and its current mean and covariance
+__device__ inline void ekf_update(Slot& d, const Predicted& pr, const M2& H, double zr, double zphi, double w_max) {
+  const M2 iq{pr.q00, pr.q01, pr.q10, pr.q11};
+  const M2 K = mul(mul(d.C, tr(H)), iq);       // :360
+  const double e0 = zr - pr.fr;
+  const double e1 = wrap_residual(zphi - pr.fphi);
+  d.m0 = d.m0 + (K.a * e0 + K.b * e1);         // :369
+  d.m1 = d.m1 + (K.c * e0 + K.d * e1);
+  const M2 KH = mul(K, H);
   const M2 IKH{1.0 - KH.a, 0.0 - KH.b, 0.0 - KH.c, 1.0 - KH.d};
-  const M2 Cn = mul(IKH, d.C);                 // :370
-  FLD(f, F_C00) = Cn.a; FLD(f, F_C01) = Cn.b; FLD(f, F_C10) = Cn.c; FLD(f, F_C11) = Cn.d;
-  // whole 16-byte pairs are written (the untouched halves with what was read): no partial lines
-  FLD(f, F_W) = w_max;
-  FLD_I(f, F_INT, 0) = d.cnt + 1; FLD_I(f, F_INT, 1) = d.id;
-  FLD(sc, S_DET) = d.det;
-  FLD_I(sc, S_UPD, 0) = 1; FLD_I(sc, S_UPD, 1) = 0;
+  d.C = mul(IKH, d.C);                         // :370
+  d.w = w_max;
+  d.cnt = d.cnt + 1;
+  d.id = d.id | kUpdBit;
 }
 
 #ifndef FS_APPLY_WAVES
-#define FS_APPLY_WAVES 3
+#define FS_APPLY_WAVES 2
 #endif
+#ifndef FS_APPLY_BATCH
+#define FS_APPLY_BATCH 4
+#endif
+// The picks of all measurements are staged in LDS.  Two passes over a per-thread bit set of feature slots
+// ((F + 31) / 32 words per thread, all zero before and after) tell for every measurement whether an earlier
+// one picked the same feature (it is then applied together with that one, wherever in the list it stands)
+// and whether a later one did.  First picks go in batches: the slots and measurements of a batch are
+// loaded together, then predicted, updated and stored.
+// Dynamic LDS: marks [blocks of 64 measurements][3][128] u64, bit sets [words][128] u32, picks [measurements, rounded
+// up to 16][128] i16.
+__host__ __device__ inline size_t fs_apply_lds_bytes(int F, int nv) {
+  const size_t nblk = (size_t)(nv + 63) / 64;
+  return (size_t)((F + 31) / 32) * 128 * 4 + nblk * 3 * 128 * 8 + (size_t)((nv + 15) & ~15) * 128 * 2;
+}
 __global__ __launch_bounds__(128, FS_APPLY_WAVES) void fs_apply_kernel(const FsParams P) {
-  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P.M) return;
+  extern __shared__ __align__(16) unsigned char fs_apply_lds[];
+  const int tid = threadIdx.x;
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + tid;
   const int nv = P.L;
+  const int nwords = (P.F + 31) >> 5, nblk = (nv + 63) >> 6;
+  unsigned long long* const s_mark = reinterpret_cast<unsigned long long*>(fs_apply_lds);          // [nblk][3][128]: later, first, birth
+  unsigned int* const s_bits = reinterpret_cast<unsigned int*>(s_mark + (size_t)nblk * 3 * 128);   // [nwords][128]
+  short* const s_pick = reinterpret_cast<short*>(s_bits + (size_t)nwords * 128);                   // [nv rounded up to 16][128]
+  if (p >= P.M) return;
+  for (int w = 0; w < nwords; ++w) s_bits[w * 128 + tid] = 0u;
   const double x = P.x[p], y = P.y[p], th = P.th[p];
   int n = P.nfeat[p];
   int32_t new_id = P.new_id[p];
-  for (int base = 0; base < nv; base += 64) {
-    const int top = min(nv, base + 64);
-    // updates: the measurement two steps ahead and the feature of the next step are on their way while
-    // this step computes; a feature picked twice in a row is read again after its stores
-    unsigned long long births = 0;
-    MeasRec m1 = load_meas(MREC(base));
-    MeasRec m2 = base + 1 < top ? load_meas(MREC(base + 1)) : MeasRec{-2, 0.0, 0.0, 0.0};
-    SlotData s1 = {};
-    if (m1.c >= 0) s1 = load_slot(FREC(m1.c), SREC(m1.c));
-    for (int u = base; u < top; ++u) {
-      const MeasRec cur = m1;
-      const SlotData cs = s1;
-      m1 = m2;
-      m2 = u + 2 < top ? load_meas(MREC(u + 2)) : MeasRec{-2, 0.0, 0.0, 0.0};
-      const bool again = m1.c == cur.c;
-      if (m1.c >= 0 && !again) s1 = load_slot(FREC(m1.c), SREC(m1.c));
-      if (cur.c >= 0) update_feature(FREC(cur.c), SREC(cur.c), cs, cur.zr, cur.zphi, cur.bw);
-      if (cur.c == -1) births |= 1ull << (u - base);
-      if (m1.c >= 0 && again) s1 = load_slot(FREC(m1.c), SREC(m1.c));
+  constexpr int kB = FS_APPLY_BATCH;
+  // the picks: independent loads, many in flight (a position past the last repeats the last)
+#pragma unroll 16
+  for (int k = 0; k < ((nv + 15) & ~15); ++k) s_pick[k * 128 + tid] = (short)FLD_I(MREC(min(k, nv - 1)), M_BC, 0);
+  // later: another measurement further on picks the same feature
+  for (int blk = nblk - 1; blk >= 0; --blk) {
+    unsigned long long later = 0;
+    for (int k = min(nv - (blk << 6), 64) - 1; k >= 0; --k) {
+      const int c = s_pick[((blk << 6) + k) * 128 + tid];
+      if (c >= 0) {
+        const unsigned int w = s_bits[(c >> 5) * 128 + tid], bit = 1u << (c & 31);
+        if (w & bit) later |= 1ull << k;
+        else s_bits[(c >> 5) * 128 + tid] = w | bit;
+      }
+    }
+    s_mark[(blk * 3 + 0) * 128 + tid] = later;
+  }
+  // first: the first pick of its feature (clears the set again); birth: no feature passed the gate
+  for (int blk = 0; blk < nblk; ++blk) {
+    unsigned long long first = 0, birth = 0;
+    const int cnt = min(nv - (blk << 6), 64);
+    for (int k = 0; k < cnt; ++k) {
+      const int c = s_pick[((blk << 6) + k) * 128 + tid];
+      if (c >= 0) {
+        const unsigned int w = s_bits[(c >> 5) * 128 + tid], bit = 1u << (c & 31);
+        if (w & bit) { s_bits[(c >> 5) * 128 + tid] = w & ~bit; first |= 1ull << k; }
+      } else if (c == -1) {
+        birth |= 1ull << k;
+      }
+    }
+    s_mark[(blk * 3 + 1) * 128 + tid] = first;
+    s_mark[(blk * 3 + 2) * 128 + tid] = birth;
+  }
+  for (int blk = 0; blk < nblk; ++blk) {
+    const int base = blk << 6;
+    const unsigned long long later = s_mark[(blk * 3 + 0) * 128 + tid];
+    unsigned long long todo = s_mark[(blk * 3 + 1) * 128 + tid], births = s_mark[(blk * 3 + 2) * 128 + tid];
+    // first picks in batches: the slots and measurements of a batch are loaded together
+    while (todo) {
+      int kk[kB], cc[kB];
+      Slot sl[kB];
+      double zr[kB], zp[kB], bw[kB];
+#pragma unroll
+      for (int b = 0; b < kB; ++b) {
+        kk[b] = -1; cc[b] = 0;
+        sl[b] = Slot{1.0, 0.0, M2{1.0, 0.0, 0.0, 1.0}, 0.0, 0, 0};   // an empty place in the batch computes on harmless values
+        zr[b] = zp[b] = bw[b] = 0.0;
+        if (todo) {
+          kk[b] = __ffsll((long long)todo) - 1;
+          todo &= todo - 1;
+          cc[b] = s_pick[(base + kk[b]) * 128 + tid];
+          sl[b] = load_slot(FREC(cc[b]));
+          const double* m = MREC(base + kk[b]);
+          zr[b] = FLD(m, M_ZR); zp[b] = FLD(m, M_ZPHI); bw[b] = FLD(m, M_BW);
+        }
+      }
+      // the predictions and updates of a batch are independent chains of dependent float64 operations:
+      // written without branches so that they interleave
+      Predicted pr[kB];
+      M2 H[kB];
+#pragma unroll
+      for (int b = 0; b < kB; ++b)
+        pr[b] = predict_feature(RawFeat{sl[b].m0, sl[b].m1, sl[b].C.a, sl[b].C.b, sl[b].C.c, sl[b].C.d}, x, y, th, P.qt_r,
+                                P.qt_phi, &H[b]);
+#pragma unroll
+      for (int b = 0; b < kB; ++b) ekf_update(sl[b], pr[b], H[b], zr[b], zp[b], bw[b]);
+#pragma unroll
+      for (int b = 0; b < kB; ++b) {
+        if (kk[b] >= 0 && ((later >> kk[b]) & 1ull)) {   // rare: the other measurements that picked this feature, in order
+          for (int u2 = base + kk[b] + 1; u2 < nv; ++u2) {
+            if (s_pick[u2 * 128 + tid] == cc[b]) {
+              const double* m = MREC(u2);
+              ekf_update(sl[b], pr[b], H[b], FLD(m, M_ZR), FLD(m, M_ZPHI), FLD(m, M_BW));
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < kB; ++b)
+        if (kk[b] >= 0) store_slot(FREC(cc[b]), sl[b]);
     }
     // births (:318-347), in landmark order
     while (births) {
@@ -401,7 +508,7 @@ __global__ __launch_bounds__(128, FS_APPLY_WAVES) void fs_apply_kernel(const FsP
       births &= births - 1;
       if (n >= P.F) { atomicMax(P.overflow, 1); continue; }
       const double* m = MREC(u);
-      create_feature(FREC(n), SREC(n), new_id++, FLD(m, M_ZR), FLD(m, M_ZPHI), x, y, th, P.qt_r, P.qt_phi, P.p0);
+      create_feature(FREC(n), new_id++, FLD(m, M_ZR), FLD(m, M_ZPHI), x, y, th, P.qt_r, P.qt_phi, P.p0);
       ++n;
     }
   }
@@ -425,7 +532,7 @@ __global__ __launch_bounds__(128) void fs_decay_kernel(const FsParams P) {
     bool keep = true;
     if (slid) {
       slid = false;
-    } else if (FLD_I(SREC(j), S_UPD, 0)) {
+    } else if (FLD_I(f, F_INT, 1) & kUpdBit) {
       wgt = wgt * FLD(f, F_W);
       ++n_assoc;
     } else {
@@ -465,7 +572,8 @@ __global__ void fs_gather_kernel(const int64_t* __restrict__ idx, int64_t M, int
   const double* a = in + tile_word(src, F, slot, F_WORDS);
   double* b = out + tile_word(p, F, slot, F_WORDS);
 #pragma unroll
-  for (int w = 0; w < F_WORDS; ++w) FLD(b, w) = FLD(a, w);
+  for (int w = 0; w < F_WORDS; ++w)   // the copy starts the next step as "not updated": sign bit of the counter word off
+    FLD(b, w) = (w == F_INT) ? __longlong_as_double(__double_as_longlong(FLD(a, w)) & kUpdMask64) : FLD(a, w);
 }
 
 __global__ void fs_total_kernel(const double* __restrict__ cdf, int64_t n, double floor_value, double* __restrict__ scal) {
@@ -496,7 +604,7 @@ __global__ void fs_pack_rows_kernel(int64_t lo, int64_t n, int F, const int32_t*
 #pragma unroll
   for (int w = 0; w < 7; ++w) dst[w] = (unsigned long long)__double_as_longlong(FLD(f, w));
   dst[7] = (unsigned long long)(long long)FLD_I(f, F_INT, 0);
-  dst[8] = (unsigned long long)(long long)FLD_I(f, F_INT, 1);
+  dst[8] = (unsigned long long)(long long)(FLD_I(f, F_INT, 1) & ~kUpdBit);
 }
 
 __global__ void fs_unpack_rows_kernel(const int64_t* __restrict__ idx, int64_t row0_global, int64_t L, int64_t M, int F,
@@ -532,10 +640,10 @@ struct FsState {
   double* feat[2] = {nullptr, nullptr};   // feature slots, double-buffered for the gather
   int32_t* nfeat[2] = {nullptr, nullptr};
   int32_t* newid[2] = {nullptr, nullptr};
-  double* scr = nullptr;                  // per-step predictions
   double* meas = nullptr; int mcap = 0;   // per-step measurements, mcap rows per tile
   double* noise = nullptr;
   double* d_truth = nullptr; int truth_cap = 0;   // (r, phi) of the landmarks in range, padded to a multiple of eight
+  unsigned long long* d_sectors = nullptr;        // landmark sets per bearing sector and block of 64, then one set of all per block
   int32_t* overflow = nullptr;
   int16_t* d_ints = nullptr; double* d_normals = nullptr; int64_t normals_cap = 0;
   unsigned long long* stage = nullptr; int64_t stage_words = 0;   // feature rows on their way to / from another rank
@@ -544,7 +652,7 @@ struct FsState {
 
 static void fs_free(FsState* s) {
   if (!s) return;
-  void* all[] = {s->feat[0], s->feat[1], s->nfeat[0], s->nfeat[1], s->newid[0], s->newid[1], s->scr, s->meas, s->noise, s->d_truth,
+  void* all[] = {s->feat[0], s->feat[1], s->nfeat[0], s->nfeat[1], s->newid[0], s->newid[1], s->meas, s->noise, s->d_truth, s->d_sectors,
                  s->overflow, s->d_ints, s->d_normals, s->stage};
   for (void* q : all) if (q) (void)hipFree(q);
   delete s;
@@ -567,7 +675,7 @@ static int fs_stage(mclhip_ctx* c, FsState* s, int64_t words) {
 #define F_TRY(expr) do { int rc__ = (expr); if (rc__ != MCLHIP_OK) return rc__; } while (0)
 #define F_HIP(expr) MCL_HIP(c, expr)
 
-// uploads the step's inputs and enqueues the three per-particle kernels (pose sample .. weight / decay pass)
+// uploads the step's inputs and enqueues the per-particle kernels (pose sample .. weight / decay pass)
 static int fs_enqueue_kernel(mclhip_ctx* c, double v, double omega, double dt, const double alpha[6], const double* truth_r,
                              const double* truth_phi, const uint8_t* truth_valid, int L, const int16_t* ints,
                              const double* normals, uint64_t seed) {
@@ -589,15 +697,32 @@ static int fs_enqueue_kernel(mclhip_ctx* c, double v, double omega, double dt, c
     F_HIP(hipStreamSynchronize(c->stream));
     if (s->d_truth) (void)hipFree(s->d_truth);
     if (s->meas) (void)hipFree(s->meas);
-    s->d_truth = s->meas = nullptr; s->truth_cap = s->mcap = 0;
+    if (s->d_sectors) (void)hipFree(s->d_sectors);
+    s->d_truth = s->meas = nullptr; s->d_sectors = nullptr; s->truth_cap = s->mcap = 0;
     const int cap = ((n_valid + n_valid / 4 + 8) + 7) & ~7;
     F_HIP(hipMalloc((void**)&s->d_truth, (size_t)2 * cap * sizeof(double)));
+    F_HIP(hipMalloc((void**)&s->d_sectors, (size_t)((cap + 63) / 64) * (kSectors + 1) * sizeof(unsigned long long)));
     F_HIP(hipMalloc((void**)&s->meas, (size_t)s->tiles * cap * M_WORDS * 64 * sizeof(double)));
     s->truth_cap = s->mcap = cap;
   }
+  const int n_blk = (n_valid + 63) / 64;
   if (!near.empty()) {
+    // the association sweep's index: which landmarks of every block of 64 have their bearing in which sector of the circle
+    std::vector<unsigned long long> sect((size_t)n_blk * (kSectors + 1), 0ull);
+    for (int u = 0; u < n_valid; ++u) {
+      const double phi = near[2 * u + 1];
+      const unsigned long long bit = 1ull << (u & 63);
+      sect[(size_t)n_blk * kSectors + (u >> 6)] |= bit;
+      if (std::fabs(phi) < 1.0e6) {
+        const int b = (int)std::floor((phi + M_PI) * ((double)kSectors / (2.0 * M_PI)));   // the kernel's own expression
+        sect[(size_t)(u >> 6) * kSectors + (b & (kSectors - 1))] |= bit;
+      } else {
+        for (int b = 0; b < kSectors; ++b) sect[(size_t)(u >> 6) * kSectors + b] |= bit;    // no bearing to file it under
+      }
+    }
     F_HIP(hipMemcpyAsync(s->d_truth, near.data(), near.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    F_HIP(hipStreamSynchronize(c->stream));   // `near` is a local
+    F_HIP(hipMemcpyAsync(s->d_sectors, sect.data(), sect.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+    F_HIP(hipStreamSynchronize(c->stream));   // the tables are locals
   }
   if (ints) {
     if (!s->d_ints) F_HIP(hipMalloc((void**)&s->d_ints, (size_t)M * 36 * sizeof(int16_t)));
@@ -629,14 +754,24 @@ static int fs_enqueue_kernel(mclhip_ctx* c, double v, double omega, double dt, c
   P.index0 = c->first_index;
   P.x = (double*)c->px[c->cur]; P.y = (double*)c->py[c->cur]; P.th = (double*)c->pth[c->cur]; P.wout = c->w[c->cur];
   P.nfeat = s->nfeat[a]; P.new_id = s->newid[a];
-  P.feat = s->feat[a]; P.scr = s->scr; P.meas = s->meas; P.noise = s->noise;
+  P.feat = s->feat[a]; P.meas = s->meas; P.noise = s->noise;
   P.overflow = s->overflow;
+  P.sectors = s->d_sectors;
+  P.far_r = 0.0;
+  for (int u = 0; u < n_valid; ++u) P.far_r = std::max(P.far_r, near[2 * u]);
   const dim3 fs_grid((unsigned)((M + 127) / 128));
-  hipLaunchKernelGGL(fs_predict_kernel, fs_grid, dim3(128), 0, c->stream, P);
+  hipLaunchKernelGGL(fs_pose_kernel, fs_grid, dim3(128), 0, c->stream, P);
   if (n_valid > 0) {
     hipLaunchKernelGGL(fs_draw_kernel, fs_grid, dim3(128), 0, c->stream, P, (const double2*)s->d_truth);
-    hipLaunchKernelGGL(fs_associate_kernel, fs_grid, dim3(128), 0, c->stream, P, (const double2*)s->d_truth);
-    hipLaunchKernelGGL(fs_apply_kernel, fs_grid, dim3(128), 0, c->stream, P);
+    const size_t assoc_lds = near.size() * sizeof(double) + (size_t)n_blk * (kSectors + 1) * sizeof(unsigned long long);
+    if (assoc_lds > 60 * 1024) return fail(c, MCLHIP_E_LIMIT, "more landmarks in range than the association kernel's table holds");
+    hipLaunchKernelGGL(fs_associate_kernel, fs_grid, dim3(128), assoc_lds, c->stream, P, (const double2*)s->d_truth);
+    const size_t apply_lds = fs_apply_lds_bytes(s->F, n_valid);
+    if (apply_lds > 160 * 1024) return fail(c, MCLHIP_E_LIMIT, "more landmarks in range (or feature slots) than the update kernel's LDS tables hold");
+    if (apply_lds > 48 * 1024)
+      F_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fs_apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)apply_lds));
+    hipLaunchKernelGGL(fs_apply_kernel, fs_grid, dim3(128), apply_lds, c->stream, P);
   }
   hipLaunchKernelGGL(fs_decay_kernel, fs_grid, dim3(128), 0, c->stream, P);
   F_HIP(hipGetLastError());
@@ -665,7 +800,6 @@ int mclhip_fs_init(mclhip_ctx* c, int64_t M, int capacity) {
     F_HIP(hipMemset(s->nfeat[b], 0, M * sizeof(int32_t)));
     F_HIP(hipMemset(s->newid[b], 0, M * sizeof(int32_t)));
   }
-  F_HIP(hipMalloc((void**)&s->scr, slots * S_WORDS * sizeof(double)));
   F_HIP(hipMalloc((void**)&s->noise, (size_t)2 * M * sizeof(double)));
   F_HIP(hipMalloc((void**)&s->overflow, sizeof(int32_t)));
   F_HIP(hipMemset(s->overflow, 0, sizeof(int32_t)));
@@ -734,7 +868,7 @@ int mclhip_fs_get_state(mclhip_ctx* c, double* pose, double* w, int32_t* nfeat, 
         if (f_cov) for (int q = 0; q < 4; ++q) f_cov[o * 4 + q] = live ? FLD(f, F_C00 + q) : 0.0;
         if (f_w) f_w[o] = live ? FLD(f, F_W) : 0.0;
         if (f_i) f_i[o] = live ? halves[0] : 0;
-        if (f_id) f_id[o] = live ? halves[1] : -1;
+        if (f_id) f_id[o] = live ? (halves[1] & 0x7fffffff) : -1;
       }
   }
   return MCLHIP_OK;

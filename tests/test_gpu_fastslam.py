@@ -163,3 +163,30 @@ def test_two_measurements_that_pick_the_same_feature():
             doubles += int(np.sum(s["f_i"] - prev_i[idx] >= 2))
         prev_i = s["f_i"]
     assert doubles > 20, doubles     # the case this test is about did occur
+
+
+def test_dense_landmark_field_against_the_oracle():
+    """256 landmarks, about a quarter of them in range at a time (the layout of the large timing
+    configuration): the association sweep's landmark index by bearing and its range pre-test see
+    windows that wrap around the circle and features far out of range."""
+    from slam_amd import _lib as L
+    M, nl, cap = 128, 256, 160
+    rng = np.random.RandomState(9)
+    lm = np.stack([rng.uniform(-8, 33, nl), rng.uniform(-24, 8, nl), np.zeros(nl)], 1).astype(np.float32)
+    ctx = L.Context(0, L.F64)
+    ctx.fs_init(M, cap)
+    orc = F.OracleFastSLAM(M, lm)
+    x_gt = [0, 0, 0]
+    for t in range(7):
+        ut = [25, 0.001] if t % 5 else [25, -np.pi / 2 * 5]
+        x_gt = F.true_pose_step(x_gt, ut)
+        tr, tp, tv = _truth(x_gt, lm)
+        nv = int(tv.sum())
+        ints = rng.randint(-1000, 1000, size=(M, 3, 12)).astype(np.int16)
+        normals = rng.randn(M, 2 * nv)
+        ru = float(rng.rand())
+        idx = ctx.fs_step(ut[0], ut[1], F.DT, F.ALPHA, tr, tp, tv, ints, normals, ru / M, want_idx=True)
+        orc.step(ut, ints, normals, ru)
+        assert np.array_equal(idx, orc.last_idx), t
+        _compare(ctx.fs_get_state(), orc.state(cap), t)
+    assert nv > 40 and int(ctx.fs_get_state()["nfeat"].max()) > nv
