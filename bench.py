@@ -72,6 +72,27 @@ def cpu_baseline(grid, angles, X, z_meas, ut, n_particles):
                       "cost is linear in the particle count" % (n_particles, len(angles), len(orc.lut), dt)}
 
 
+def stream_copy_ceiling(torch):
+    """Measured device-to-device copy rate (bytes read + bytes written per second) of a 1-GiB buffer: what this
+    GPU's HBM delivers to the simplest streaming kernel; GB/s."""
+    n = 1 << 28
+    a = torch.empty(n, dtype=torch.float32, device="cuda")
+    b = torch.empty(n, dtype=torch.float32, device="cuda")
+    a.fill_(1.0)
+    for _ in range(3):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    reps = 10
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    del a, b
+    return 2.0 * n * 4 / (ms * 1e-3) / 1e9
+
+
 def profiled_traffic(args):
     """HBM bytes per launch of the sector-query kernel from the committed rocprofv3 counter passes
     (profiles/rNN_pmc_per_kernel.json; FETCH_SIZE and WRITE_SIZE are in KiB, collected in separate
@@ -174,6 +195,7 @@ def main():
     ctx.timing_enable(False)
 
     if rank == 0:
+        copy_gbs = stream_copy_ceiling(torch)
         evals_step = float(M) * world * B
         ms_step = elapsed / a.steps * 1e3
         ray_ms = ms_ray / max(n_ray, 1)
@@ -202,7 +224,9 @@ def main():
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_EVAL * float(M) * B,
                          "kernel": "raycast_kernel (sector query + beam likelihood)",
                          "kernel_ms": ray_ms, "launches": n_ray,
-                         "algorithmic_bytes_per_eval": ALGO_BYTES_PER_EVAL},
+                         "algorithmic_bytes_per_eval": ALGO_BYTES_PER_EVAL,
+                         "stream_copy_GBps": copy_gbs,
+                         "frac_of_stream_copy": (achieved / copy_gbs) if achieved else None},
             "kernel_ms": {"raycast": ray_ms, "motion": ms_mot / max(n_mot, 1),
                           "normalise+resample+gather": ms_res / max(n_res, 1)},
         }
