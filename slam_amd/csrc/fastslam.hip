@@ -1,10 +1,10 @@
 // FastSLAM 1.0 with unknown correspondence -- the reference's 13_fast_slam/fast_slam1.py
 // (fast_slam(), :240-433) on the GPU.
 //
-// One thread per particle, five kernels per filter step: pose sample (Table 5.3 with the twelve-integer
+// One thread per particle, four kernels per filter step: pose sample (Table 5.3 with the twelve-integer
 // normal sampler, :160-189); measurement draws; maximum-likelihood association of every sensed landmark
-// with a 2-sigma Mahalanobis gate (:286-315); feature birth (:318-347) or EKF update (:348-375); the weight /
-// feature-decay pass that removes from the list it iterates (:377-404).  The per-feature measurement
+// with a 2-sigma Mahalanobis gate (:286-315); one sweep over the features for the EKF updates (:348-375), the
+// births (:318-347) and the weight / feature-decay pass that removes from the list it iterates (:377-404).  The per-feature measurement
 // prediction / Jacobian / innovation covariance of :259-282 is never stored: it is a function of the
 // feature as it stood before the step and of the sampled pose, so the association sweep and the update
 // each form it from the 48 bytes of the feature they read anyway (same expressions, same results), which
@@ -35,12 +35,7 @@ namespace mcl {
 
 // fields of a feature slot (64-bit words; the last holds the two 32-bit counters)
 enum { F_M0 = 0, F_M1, F_C00, F_C01, F_C10, F_C11, F_W, F_INT, F_WORDS };
-// "updated or created this step" (Feature.updated, :49, :280, :343, :373) is bit 31 of the id half of
-// F_INT, i.e. the sign bit of the 64-bit word: set by the update / birth, read by the decay pass, cleared
-// when the slot is copied to its descendant (gather / exchange rows); ids stay below 2^31
 constexpr int kSectors = 64;   // bearing sectors of the association sweep's landmark index (a power of two)
-constexpr int32_t kUpdBit = (int32_t)0x80000000;
-constexpr long long kUpdMask64 = 0x7fffffffffffffffll;
 // per-step measurement: (r, phi), best likelihood, best feature (-1 none, -2 out of range)
 enum { M_ZR = 0, M_ZPHI, M_BW, M_BC, M_WORDS };
 
@@ -209,14 +204,14 @@ __device__ __attribute__((noinline)) void create_feature(double* f, int32_t id, 
   FLD(f, F_M0) = m0; FLD(f, F_M1) = m1;
   FLD(f, F_C00) = C.a; FLD(f, F_C01) = C.b; FLD(f, F_C10) = C.c; FLD(f, F_C11) = C.d;
   FLD(f, F_W) = p0;
-  FLD_I(f, F_INT, 0) = 1; FLD_I(f, F_INT, 1) = id | kUpdBit;
+  FLD_I(f, F_INT, 0) = 1; FLD_I(f, F_INT, 1) = id;
 }
 
 // ---- every landmark: draw the measurement, associate, create or update (:286-375) ----
 // The association of a measurement reads only the prediction of the features that existed before this
 // step, never what an earlier measurement of the same step changed.  So all measurements of the step are
 // drawn first and parked in device memory (fs_draw_kernel), ONE sweep over the stored features associates
-// them all (fs_associate_kernel), and then they are applied (fs_apply_kernel): updates feature by feature
+// them all (fs_associate_kernel), and then they are applied (fs_update_kernel): updates feature by feature
 // -- two measurements may pick the same feature: they are applied one after the other, in landmark order,
 // with the one prediction -- and births in landmark order; an update touches a feature that existed
 // before the step, a birth a new slot, so the two do not meet.
@@ -387,175 +382,146 @@ __device__ inline void ekf_update(Slot& d, const Predicted& pr, const M2& H, dou
   d.C = mul(IKH, d.C);                         // :370
   d.w = w_max;
   d.cnt = d.cnt + 1;
-  d.id = d.id | kUpdBit;
 }
 
-#ifndef FS_APPLY_WAVES
-#define FS_APPLY_WAVES 2
+#ifndef FS_UPDATE_WAVES
+#define FS_UPDATE_WAVES 3
 #endif
-#ifndef FS_APPLY_BATCH
-#define FS_APPLY_BATCH 4
-#endif
-// The picks of all measurements are staged in LDS.  Two passes over a per-thread bit set of feature slots
-// ((F + 31) / 32 words per thread, all zero before and after) tell for every measurement whether an earlier
-// one picked the same feature (it is then applied together with that one, wherever in the list it stands)
-// and whether a later one did.  First picks go in batches: the slots and measurements of a batch are
-// loaded together, then predicted, updated and stored.
-// Dynamic LDS: marks [blocks of 64 measurements][3][128] u64, bit sets [words][128] u32, picks [measurements, rounded
-// up to 16][128] i16.
-__host__ __device__ inline size_t fs_apply_lds_bytes(int F, int nv) {
-  const size_t nblk = (size_t)(nv + 63) / 64;
-  return (size_t)((F + 31) / 32) * 128 * 4 + nblk * 3 * 128 * 8 + (size_t)((nv + 15) & ~15) * 128 * 2;
-}
-__global__ __launch_bounds__(128, FS_APPLY_WAVES) void fs_apply_kernel(const FsParams P) {
-  extern __shared__ __align__(16) unsigned char fs_apply_lds[];
+// ---- EKF updates (:348-375), births (:318-347) and the weight / feature-decay pass (:377-404) as ONE sweep
+// over the particle's features in list order.  What a feature needs to know -- which measurement picked it --
+// is the inverse of the association, built per thread in LDS (per live slot the first measurement that picked
+// it, per measurement the next one that picked the same feature); the sweep then reads every slot once, a step ahead of its use, and
+// writes it once, closing ranks over discarded features as it goes.  The reference removes from the list its
+// for-loop walks, so the feature that slides into a vacated slot is not visited by the pass (`slid`); births
+// stand behind the old features in the list and are visited last.
+// IT: unsigned char while fewer than 255 measurements are in range, else unsigned short.
+// Dynamic LDS: births [blocks of 64 measurements][128] u64, then the inverse [rows][128] IT, rows >= every
+// particle's feature count, then the chains [measurements][128] IT.
+template <typename IT>
+__global__ __launch_bounds__(128, FS_UPDATE_WAVES) void fs_update_kernel(const FsParams P, int rows) {
+  extern __shared__ __align__(16) unsigned char fs_update_lds[];
+  constexpr unsigned kNone = (IT)~(IT)0;
   const int tid = threadIdx.x;
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + tid;
-  const int nv = P.L;
-  const int nwords = (P.F + 31) >> 5, nblk = (nv + 63) >> 6;
-  unsigned long long* const s_mark = reinterpret_cast<unsigned long long*>(fs_apply_lds);          // [nblk][3][128]: later, first, birth
-  unsigned int* const s_bits = reinterpret_cast<unsigned int*>(s_mark + (size_t)nblk * 3 * 128);   // [nwords][128]
-  short* const s_pick = reinterpret_cast<short*>(s_bits + (size_t)nwords * 128);                   // [nv rounded up to 16][128]
   if (p >= P.M) return;
-  for (int w = 0; w < nwords; ++w) s_bits[w * 128 + tid] = 0u;
+  const int nv = P.L, nblk = (nv + 63) >> 6;
+  unsigned long long* const s_birth = reinterpret_cast<unsigned long long*>(fs_update_lds);   // [nblk][128]
+  IT* const s_inv = reinterpret_cast<IT*>(s_birth + (size_t)nblk * 128);                     // [rows][128]
+  IT* const s_next = s_inv + (size_t)rows * 128;                                              // [nv][128]
   const double x = P.x[p], y = P.y[p], th = P.th[p];
-  int n = P.nfeat[p];
+  const int n_old = min(P.nfeat[p], rows);
   int32_t new_id = P.new_id[p];
-  constexpr int kB = FS_APPLY_BATCH;
-  // the picks: independent loads, many in flight (a position past the last repeats the last)
-#pragma unroll 16
-  for (int k = 0; k < ((nv + 15) & ~15); ++k) s_pick[k * 128 + tid] = (short)FLD_I(MREC(min(k, nv - 1)), M_BC, 0);
-  // later: another measurement further on picks the same feature
+  for (int j = 0; j < n_old; ++j) s_inv[j * 128 + tid] = (IT)kNone;
+  // the association, inverted: sixteen picks are read together, then filed -- last measurement first, so that a
+  // slot ends up with its first picker and every picker points to the next one of the same feature
   for (int blk = nblk - 1; blk >= 0; --blk) {
-    unsigned long long later = 0;
-    for (int k = min(nv - (blk << 6), 64) - 1; k >= 0; --k) {
-      const int c = s_pick[((blk << 6) + k) * 128 + tid];
-      if (c >= 0) {
-        const unsigned int w = s_bits[(c >> 5) * 128 + tid], bit = 1u << (c & 31);
-        if (w & bit) later |= 1ull << k;
-        else s_bits[(c >> 5) * 128 + tid] = w | bit;
-      }
-    }
-    s_mark[(blk * 3 + 0) * 128 + tid] = later;
-  }
-  // first: the first pick of its feature (clears the set again); birth: no feature passed the gate
-  for (int blk = 0; blk < nblk; ++blk) {
-    unsigned long long first = 0, birth = 0;
-    const int cnt = min(nv - (blk << 6), 64);
-    for (int k = 0; k < cnt; ++k) {
-      const int c = s_pick[((blk << 6) + k) * 128 + tid];
-      if (c >= 0) {
-        const unsigned int w = s_bits[(c >> 5) * 128 + tid], bit = 1u << (c & 31);
-        if (w & bit) { s_bits[(c >> 5) * 128 + tid] = w & ~bit; first |= 1ull << k; }
-      } else if (c == -1) {
-        birth |= 1ull << k;
-      }
-    }
-    s_mark[(blk * 3 + 1) * 128 + tid] = first;
-    s_mark[(blk * 3 + 2) * 128 + tid] = birth;
-  }
-  for (int blk = 0; blk < nblk; ++blk) {
-    const int base = blk << 6;
-    const unsigned long long later = s_mark[(blk * 3 + 0) * 128 + tid];
-    unsigned long long todo = s_mark[(blk * 3 + 1) * 128 + tid], births = s_mark[(blk * 3 + 2) * 128 + tid];
-    // first picks in batches: the slots and measurements of a batch are loaded together
-    while (todo) {
-      int kk[kB], cc[kB];
-      Slot sl[kB];
-      double zr[kB], zp[kB], bw[kB];
+    unsigned long long birth = 0;
+    const int k_end = min(nv, (blk + 1) << 6);
+    for (int k0 = (blk << 6) + ((k_end - 1 - (blk << 6)) & ~15); k0 >= (blk << 6); k0 -= 16) {
+      int c[16];
 #pragma unroll
-      for (int b = 0; b < kB; ++b) {
-        kk[b] = -1; cc[b] = 0;
-        sl[b] = Slot{1.0, 0.0, M2{1.0, 0.0, 0.0, 1.0}, 0.0, 0, 0};   // an empty place in the batch computes on harmless values
-        zr[b] = zp[b] = bw[b] = 0.0;
-        if (todo) {
-          kk[b] = __ffsll((long long)todo) - 1;
-          todo &= todo - 1;
-          cc[b] = s_pick[(base + kk[b]) * 128 + tid];
-          sl[b] = load_slot(FREC(cc[b]));
-          const double* m = MREC(base + kk[b]);
-          zr[b] = FLD(m, M_ZR); zp[b] = FLD(m, M_ZPHI); bw[b] = FLD(m, M_BW);
-        }
-      }
-      // the predictions and updates of a batch are independent chains of dependent float64 operations:
-      // written without branches so that they interleave
-      Predicted pr[kB];
-      M2 H[kB];
+      for (int k = 0; k < 16; ++k) c[k] = FLD_I(MREC(min(k0 + k, nv - 1)), M_BC, 0);
 #pragma unroll
-      for (int b = 0; b < kB; ++b)
-        pr[b] = predict_feature(RawFeat{sl[b].m0, sl[b].m1, sl[b].C.a, sl[b].C.b, sl[b].C.c, sl[b].C.d}, x, y, th, P.qt_r,
-                                P.qt_phi, &H[b]);
-#pragma unroll
-      for (int b = 0; b < kB; ++b) ekf_update(sl[b], pr[b], H[b], zr[b], zp[b], bw[b]);
-#pragma unroll
-      for (int b = 0; b < kB; ++b) {
-        if (kk[b] >= 0 && ((later >> kk[b]) & 1ull)) {   // rare: the other measurements that picked this feature, in order
-          for (int u2 = base + kk[b] + 1; u2 < nv; ++u2) {
-            if (s_pick[u2 * 128 + tid] == cc[b]) {
-              const double* m = MREC(u2);
-              ekf_update(sl[b], pr[b], H[b], FLD(m, M_ZR), FLD(m, M_ZPHI), FLD(m, M_BW));
-            }
+      for (int k = 15; k >= 0; --k) {
+        if (k0 + k < nv) {
+          if (c[k] >= 0 && c[k] < n_old) {
+            s_next[(k0 + k) * 128 + tid] = s_inv[c[k] * 128 + tid];
+            s_inv[c[k] * 128 + tid] = (IT)(k0 + k);
+          } else if (c[k] == -1) {
+            birth |= 1ull << ((k0 + k) & 63);
           }
         }
       }
-#pragma unroll
-      for (int b = 0; b < kB; ++b)
-        if (kk[b] >= 0) store_slot(FREC(cc[b]), sl[b]);
     }
-    // births (:318-347), in landmark order
-    while (births) {
-      const int u = base + __ffsll((long long)births) - 1;
-      births &= births - 1;
-      if (n >= P.F) { atomicMax(P.overflow, 1); continue; }
-      const double* m = MREC(u);
-      create_feature(FREC(n), new_id++, FLD(m, M_ZR), FLD(m, M_ZPHI), x, y, th, P.qt_r, P.qt_phi, P.p0);
-      ++n;
-    }
+    s_birth[blk * 128 + tid] = birth;
   }
-  P.nfeat[p] = n;
-  P.new_id[p] = new_id;
-}
-
-// ---- weight and feature decay (:377-404).  The reference removes from the list its for-loop
-// walks, so the feature that slides into a vacated slot is not visited in this pass. ----
-__global__ __launch_bounds__(128) void fs_decay_kernel(const FsParams P) {
-  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P.M) return;
-  const double x = P.x[p], y = P.y[p];
-  const int n = P.nfeat[p];
   double wgt = 1.0;
   int n_assoc = 0;
   int kept = 0;            // slots written so far: survivors close ranks as the pass goes
   bool slid = false;       // the previous feature was discarded, this one takes its place unvisited
-  for (int j = 0; j < n; ++j) {
-    double* f = FREC(j);
-    bool keep = true;
+  // slot j + 1 and the measurement that picked it are on their way while slot j is worked on
+  Slot nxt = {};
+  unsigned e_nxt = kNone;
+  double zr_n = 0.0, zp_n = 0.0, bw_n = 0.0;
+  if (n_old > 0) {
+    nxt = load_slot(FREC(0));
+    e_nxt = s_inv[tid];
+    if (e_nxt != kNone) { const double* m = MREC(e_nxt); zr_n = FLD(m, M_ZR); zp_n = FLD(m, M_ZPHI); bw_n = FLD(m, M_BW); }
+  }
+  for (int j = 0; j < n_old; ++j) {
+    Slot cur = nxt;
+    const unsigned e = e_nxt;
+    const double zr = zr_n, zp = zp_n, bw = bw_n;
+    if (j + 1 < n_old) {
+      nxt = load_slot(FREC(j + 1));
+      e_nxt = s_inv[(j + 1) * 128 + tid];
+      if (e_nxt != kNone) { const double* m = MREC(e_nxt); zr_n = FLD(m, M_ZR); zp_n = FLD(m, M_ZPHI); bw_n = FLD(m, M_BW); }
+    }
+    const bool upd = e != kNone;
+    if (upd) {
+      M2 H;
+      const Predicted pr = predict_feature(RawFeat{cur.m0, cur.m1, cur.C.a, cur.C.b, cur.C.c, cur.C.d}, x, y, th, P.qt_r, P.qt_phi, &H);
+      ekf_update(cur, pr, H, zr, zp, bw);
+      // rare: the other measurements that picked this feature, in landmark order, same prediction
+      for (unsigned u2 = s_next[e * 128 + tid]; u2 != kNone; u2 = s_next[u2 * 128 + tid]) {
+        const double* m = MREC(u2);
+        ekf_update(cur, pr, H, FLD(m, M_ZR), FLD(m, M_ZPHI), FLD(m, M_BW));
+      }
+    }
+    bool keep = true, touched = upd;
     if (slid) {
       slid = false;
-    } else if (FLD_I(f, F_INT, 1) & kUpdBit) {
-      wgt = wgt * FLD(f, F_W);
+    } else if (upd) {
+      wgt = wgt * cur.w;
       ++n_assoc;
     } else {
-      const double dx = FLD(f, F_M0) - x, dy = FLD(f, F_M1) - y;
-      FLD(f, F_W) = P.p0;
+      const double dx = cur.m0 - x, dy = cur.m1 - y;
+      cur.w = P.p0;
+      touched = true;
       if (dx * dx + dy * dy <= P.r_max2) {
-        const int cnt = FLD_I(f, F_INT, 0) - 1;
-        FLD_I(f, F_INT, 0) = cnt;
-        if (cnt < 0) { keep = false; slid = true; }   // discard
+        cur.cnt = cur.cnt - 1;
+        if (cur.cnt < 0) { keep = false; slid = true; }   // discard
       }
     }
     if (keep) {
-      if (kept != j) {
-        double* g = FREC(kept);
-#pragma unroll
-        for (int w = 0; w < F_WORDS; ++w) FLD(g, w) = FLD(f, w);
+      double* g = FREC(kept);
+      if (upd || kept != j) {
+        store_slot(g, cur);
+      } else if (touched) {                    // only the weight / counter pair changed
+        FLD(g, F_W) = cur.w;
+        FLD_I(g, F_INT, 0) = cur.cnt; FLD_I(g, F_INT, 1) = cur.id;
       }
       ++kept;
     }
   }
+  // births, in landmark order; n_list: length of the reference's list before anything is discarded
+  int n_list = n_old;
+  for (int blk = 0; blk < nblk; ++blk) {
+    unsigned long long births = s_birth[blk * 128 + tid];
+    while (births) {
+      const int u = (blk << 6) + __ffsll((long long)births) - 1;
+      births &= births - 1;
+      if (n_list >= P.F) { atomicMax(P.overflow, 1); continue; }
+      const double* m = MREC(u);
+      create_feature(FREC(kept), new_id++, FLD(m, M_ZR), FLD(m, M_ZPHI), x, y, th, P.qt_r, P.qt_phi, P.p0);
+      ++n_list;
+      ++kept;
+      if (slid) slid = false;                  // it slid into the place of a discarded feature: not visited
+      else { wgt = wgt * P.p0; ++n_assoc; }    // created this step: counts as associated with weight P0
+    }
+  }
   if (n_assoc == 0) wgt = P.p0;
   P.nfeat[p] = kept;
+  P.new_id[p] = new_id;
   P.wout[p] = wgt;
+}
+
+// largest feature count over the particles (sizes the update sweep's LDS table of the next step)
+__global__ void fs_max_count_kernel(const int32_t* __restrict__ nfeat, int64_t M, int32_t* __restrict__ out) {
+  int v = 0;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < M; p += (int64_t)gridDim.x * blockDim.x) v = max(v, nfeat[p]);
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, v);
 }
 
 // feature slots of the drawn ancestors: block row y = slot
@@ -572,8 +538,7 @@ __global__ void fs_gather_kernel(const int64_t* __restrict__ idx, int64_t M, int
   const double* a = in + tile_word(src, F, slot, F_WORDS);
   double* b = out + tile_word(p, F, slot, F_WORDS);
 #pragma unroll
-  for (int w = 0; w < F_WORDS; ++w)   // the copy starts the next step as "not updated": sign bit of the counter word off
-    FLD(b, w) = (w == F_INT) ? __longlong_as_double(__double_as_longlong(FLD(a, w)) & kUpdMask64) : FLD(a, w);
+  for (int w = 0; w < F_WORDS; ++w) FLD(b, w) = FLD(a, w);
 }
 
 __global__ void fs_total_kernel(const double* __restrict__ cdf, int64_t n, double floor_value, double* __restrict__ scal) {
@@ -604,7 +569,7 @@ __global__ void fs_pack_rows_kernel(int64_t lo, int64_t n, int F, const int32_t*
 #pragma unroll
   for (int w = 0; w < 7; ++w) dst[w] = (unsigned long long)__double_as_longlong(FLD(f, w));
   dst[7] = (unsigned long long)(long long)FLD_I(f, F_INT, 0);
-  dst[8] = (unsigned long long)(long long)(FLD_I(f, F_INT, 1) & ~kUpdBit);
+  dst[8] = (unsigned long long)(long long)FLD_I(f, F_INT, 1);
 }
 
 __global__ void fs_unpack_rows_kernel(const int64_t* __restrict__ idx, int64_t row0_global, int64_t L, int64_t M, int F,
@@ -645,6 +610,7 @@ struct FsState {
   double* d_truth = nullptr; int truth_cap = 0;   // (r, phi) of the landmarks in range, padded to a multiple of eight
   unsigned long long* d_sectors = nullptr;        // landmark sets per bearing sector and block of 64, then one set of all per block
   int32_t* overflow = nullptr;
+  int32_t* d_maxfeat = nullptr;                   // largest feature count of a particle
   int16_t* d_ints = nullptr; double* d_normals = nullptr; int64_t normals_cap = 0;
   unsigned long long* stage = nullptr; int64_t stage_words = 0;   // feature rows on their way to / from another rank
   double std_r = 0.5, std_phi = 3 * M_PI / 180.0, r_max = 10.0, p0 = 0.01, thres_sig = 2.0;
@@ -653,7 +619,7 @@ struct FsState {
 static void fs_free(FsState* s) {
   if (!s) return;
   void* all[] = {s->feat[0], s->feat[1], s->nfeat[0], s->nfeat[1], s->newid[0], s->newid[1], s->meas, s->noise, s->d_truth, s->d_sectors,
-                 s->overflow, s->d_ints, s->d_normals, s->stage};
+                 s->overflow, s->d_maxfeat, s->d_ints, s->d_normals, s->stage};
   for (void* q : all) if (q) (void)hipFree(q);
   delete s;
 }
@@ -738,6 +704,12 @@ static int fs_enqueue_kernel(mclhip_ctx* c, double v, double omega, double dt, c
     F_HIP(hipMemcpyAsync(s->d_normals, normals, (size_t)need * sizeof(double), hipMemcpyHostToDevice, c->stream));
   }
   const int a = s->cur;
+  // rows of the update sweep's LDS table: the largest feature count any particle holds
+  int32_t max_feat = 0;
+  F_HIP(hipMemsetAsync(s->d_maxfeat, 0, sizeof(int32_t), c->stream));
+  hipLaunchKernelGGL(fs_max_count_kernel, dim3((unsigned)std::min<int64_t>((M + 255) / 256, 256)), dim3(256), 0, c->stream, s->nfeat[a], M, s->d_maxfeat);
+  F_HIP(hipMemcpyAsync(&max_feat, s->d_maxfeat, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  F_HIP(hipStreamSynchronize(c->stream));
   FsParams P;
   P.M = M; P.F = s->F; P.L = n_valid; P.mcap = s->mcap;
   P.v = v; P.w = omega; P.dt = dt;
@@ -766,14 +738,26 @@ static int fs_enqueue_kernel(mclhip_ctx* c, double v, double omega, double dt, c
     const size_t assoc_lds = near.size() * sizeof(double) + (size_t)n_blk * (kSectors + 1) * sizeof(unsigned long long);
     if (assoc_lds > 60 * 1024) return fail(c, MCLHIP_E_LIMIT, "more landmarks in range than the association kernel's table holds");
     hipLaunchKernelGGL(fs_associate_kernel, fs_grid, dim3(128), assoc_lds, c->stream, P, (const double2*)s->d_truth);
-    const size_t apply_lds = fs_apply_lds_bytes(s->F, n_valid);
-    if (apply_lds > 160 * 1024) return fail(c, MCLHIP_E_LIMIT, "more landmarks in range (or feature slots) than the update kernel's LDS tables hold");
-    if (apply_lds > 48 * 1024)
-      F_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fs_apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)apply_lds));
-    hipLaunchKernelGGL(fs_apply_kernel, fs_grid, dim3(128), apply_lds, c->stream, P);
   }
-  hipLaunchKernelGGL(fs_decay_kernel, fs_grid, dim3(128), 0, c->stream, P);
+  {
+    // the sweep's inverse table has one row per feature of the particle that has most
+    const size_t entry = n_valid < 255 ? 1 : 2;
+    const int rows = std::max(max_feat, 1);
+    const size_t upd_lds = (size_t)((n_valid + 63) / 64) * 128 * sizeof(unsigned long long) + (size_t)(rows + n_valid) * 128 * entry;
+    if (n_valid >= 65535 || upd_lds > 160 * 1024)
+      return fail(c, MCLHIP_E_LIMIT, "more features per particle (or landmarks in range) than the update kernel's LDS table holds");
+    if (entry == 1) {
+      if (upd_lds > 48 * 1024)
+        F_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fs_update_kernel<unsigned char>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)upd_lds));
+      hipLaunchKernelGGL(fs_update_kernel<unsigned char>, fs_grid, dim3(128), upd_lds, c->stream, P, rows);
+    } else {
+      if (upd_lds > 48 * 1024)
+        F_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fs_update_kernel<unsigned short>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)upd_lds));
+      hipLaunchKernelGGL(fs_update_kernel<unsigned short>, fs_grid, dim3(128), upd_lds, c->stream, P, rows);
+    }
+  }
   F_HIP(hipGetLastError());
   return MCLHIP_OK;
 }
@@ -803,6 +787,7 @@ int mclhip_fs_init(mclhip_ctx* c, int64_t M, int capacity) {
   F_HIP(hipMalloc((void**)&s->noise, (size_t)2 * M * sizeof(double)));
   F_HIP(hipMalloc((void**)&s->overflow, sizeof(int32_t)));
   F_HIP(hipMemset(s->overflow, 0, sizeof(int32_t)));
+  F_HIP(hipMalloc((void**)&s->d_maxfeat, sizeof(int32_t)));
   return MCLHIP_OK;
 }
 
@@ -868,7 +853,7 @@ int mclhip_fs_get_state(mclhip_ctx* c, double* pose, double* w, int32_t* nfeat, 
         if (f_cov) for (int q = 0; q < 4; ++q) f_cov[o * 4 + q] = live ? FLD(f, F_C00 + q) : 0.0;
         if (f_w) f_w[o] = live ? FLD(f, F_W) : 0.0;
         if (f_i) f_i[o] = live ? halves[0] : 0;
-        if (f_id) f_id[o] = live ? (halves[1] & 0x7fffffff) : -1;
+        if (f_id) f_id[o] = live ? halves[1] : -1;
       }
   }
   return MCLHIP_OK;

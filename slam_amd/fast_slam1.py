@@ -134,10 +134,19 @@ class FastSLAM:
     def fast_slam(self, ut):
         """fast_slam1.py:240-433 on the GPU."""
         M = self.M
-        truth = [self._true_measurement(lm) for lm in self.landmarks]
-        tr = np.array([float(t[0]) for t in truth])
-        tp = np.array([float(t[1]) for t in truth])
-        tv = np.array([bool(0 < t[0] <= r_max) for t in truth], np.uint8)
+        if self.noise == "numpy":
+            truth = [self._true_measurement(lm) for lm in self.landmarks]       # the reference's scalar arithmetic
+            tr = np.array([float(t[0]) for t in truth])
+            tp = np.array([float(t[1]) for t in truth])
+        else:
+            # device generators: no stream to stay in step with, so the landmarks are done in one go (array
+            # arithmetic squares by multiplying where the scalar `**` goes through pow: an ulp in rare cases)
+            x, y, theta = (float(v) for v in self.x_gt[-1])
+            dx = self.landmarks[:, 0].astype(np.float64) - x
+            dy = self.landmarks[:, 1].astype(np.float64) - y
+            tr = np.sqrt(dx * dx + dy * dy)
+            tp = np.arctan2(dy, dx) - theta
+        tv = ((0 < tr) & (tr <= r_max)).astype(np.uint8)
         nv = int(tv.sum())
         ints = normals = None
         if self.noise == "numpy":

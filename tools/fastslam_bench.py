@@ -25,7 +25,7 @@ ms = float(np.median(t_all[1:])) * 1e3
 algo_bytes = M * mean_features * 64.0 * 4
 out = {"metric": "FastSLAM 1.0 particle-steps per second", "particles": M, "landmarks": NL, "value": M / (ms * 1e-3),
        "unit": "particle-steps/s", "ms_per_step": ms, "mean_features": mean_features,
-       "roofline": {"bound": "hbm", "kernel": "whole step (pose, draw, associate, apply, decay, resample + gather)",
+       "roofline": {"bound": "hbm", "kernel": "whole step (pose, draw, associate, update sweep, resample + gather)",
                     "achieved": algo_bytes / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                     "frac": algo_bytes / (ms * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_step": algo_bytes,
                     "traffic": None}}
