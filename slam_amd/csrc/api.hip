@@ -48,7 +48,7 @@ RayParams make_ray_params(const mclhip_ctx* c) {
   P.range_noise = nullptr;
   P.stamps = c->stamps;
   P.g_cell = nullptr; P.g_pk_pred = nullptr; P.g_pk = nullptr; P.g_D = 0; P.g_B0 = 0;
-  P.g_NE = 0; P.g_cls = nullptr; P.g_cls_first = nullptr; P.g_member = nullptr; P.g_mbeta = nullptr;
+  P.g_NE = 0; P.g_cls = nullptr; P.g_cls_first = nullptr; P.g_member = nullptr; P.g_ar = nullptr; P.g_thd = nullptr;
   P.no_obstacles = c->n_obstacles == 0 ? 1 : 0;
   return P;
 }

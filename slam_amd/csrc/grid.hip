@@ -338,30 +338,31 @@ int mclhip_grid_set_sensor(mclhip_ctx* c, const double* angles_deg, int B0, int 
   std::vector<uint16_t> order(NE);
   std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(), [&](uint16_t a, uint16_t b) { return red[a] < red[b]; });
-  std::vector<double> centre, mbeta(NE);
+  std::vector<double> centre, mbeta((size_t)B0 + n_dir);
   std::vector<uint32_t> cls(NE);
   std::vector<uint16_t> first, member(NE);
   for (int m = 0; m < NE; ++m) {
     const int e = order[m];
     if (centre.empty() || red[e] - centre.back() > 1e-9) { centre.push_back(red[e]); first.push_back((uint16_t)m); }
-    cls[e] = ((uint32_t)(centre.size() - 1) << 16) | (uint32_t)(e % B0);
+    cls[e] = ((uint32_t)(centre.size() - 1) << 20) | ((uint32_t)(e / B0) << 10) | (uint32_t)(e % B0);
     member[m] = (uint16_t)e;
-    mbeta[m] = tab[e];
   }
   first.push_back((uint16_t)NE);
+  for (int k = 0; k < B0; ++k) mbeta[k] = angles_deg[k] * M_PI / 180.0;                       // the two terms of robot.py:252
+  for (int d = 0; d < n_dir; ++d) mbeta[(size_t)B0 + d] = (double)d * res_theta_deg * M_PI / 180.0;
   G_TRY(set_sensor_table(c, centre.data(), (int)centre.size(), z_max, sigma_hit, lambda_short, w4, half));
   c->gl_NE = NE;
   G_TRY(galloc(c, &c->gl_cls, NE * sizeof(uint32_t)));
   G_TRY(galloc(c, &c->gl_cls_first, first.size() * sizeof(uint16_t)));
   G_TRY(galloc(c, &c->gl_member, NE * sizeof(uint16_t)));
-  G_TRY(galloc(c, &c->gl_mbeta, NE * sizeof(double)));
+  G_TRY(galloc(c, &c->gl_mbeta, mbeta.size() * sizeof(double)));
   G_TRY(galloc(c, &c->gl_zt, B0 * sizeof(double)));
   G_TRY(galloc(c, &c->gl_el, B0 * sizeof(double)));
   G_TRY(galloc(c, &c->gl_zm, B0 * sizeof(double)));
   MCL_HIP(c, hipMemcpy(c->gl_cls, cls.data(), NE * sizeof(uint32_t), hipMemcpyHostToDevice));
   MCL_HIP(c, hipMemcpy(c->gl_cls_first, first.data(), first.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   MCL_HIP(c, hipMemcpy(c->gl_member, member.data(), NE * sizeof(uint16_t), hipMemcpyHostToDevice));
-  MCL_HIP(c, hipMemcpy(c->gl_mbeta, mbeta.data(), NE * sizeof(double), hipMemcpyHostToDevice));
+  MCL_HIP(c, hipMemcpy(c->gl_mbeta, mbeta.data(), mbeta.size() * sizeof(double), hipMemcpyHostToDevice));
   c->gl_D = n_dir; c->gl_B0 = B0; c->gl_res_theta = res_theta_deg;
   c->gl_angles_deg.assign(angles_deg, angles_deg + B0);
   const size_t n = (size_t)c->H * c->W * n_dir;

@@ -57,10 +57,11 @@ struct RayParams {
   float* g_pk;                 // [H*W*D]
   int g_D, g_B0;               // headings, beams per heading
   int g_NE;                    // entries (headings x beams); the beam table proper holds their classes
-  const uint32_t* g_cls;       // [NE] class << 16 | beam of entry e
+  const uint32_t* g_cls;       // [NE] class << 20 | heading << 10 | beam of entry e
   const uint16_t* g_cls_first; // [B + 1]
   const uint16_t* g_member;    // [NE] entries by class
-  const double* g_mbeta;       // [NE] exact table angle of g_member[m]
+  const double* g_ar;          // [B0] beam angles in radians, [D] heading angles: an entry's own angle is their sum (robot.py:252)
+  const double* g_thd;
 };
 
 struct MotionParams {
@@ -170,9 +171,9 @@ struct mclhip_ctx {
   // (heading, beam) entries of the update and the classes of entries that share an absolute bearing
   int gl_NE = 0;                    // entries = headings x beams
   uint32_t* gl_cls = nullptr;       // [NE] class (position in the sorted class table) << 16 | beam k of entry e = d * B0 + k
-  uint16_t* gl_cls_first = nullptr; // [classes + 1] start of each class in gl_member / gl_mbeta
+  uint16_t* gl_cls_first = nullptr; // [classes + 1] start of each class in gl_member
   uint16_t* gl_member = nullptr;    // [NE] entries grouped by class
-  double* gl_mbeta = nullptr;       // [NE] their table angles exactly as robot.py:252 forms them (not reduced)
+  double* gl_mbeta = nullptr;       // [B0] beam angles, then [D] heading angles, in radians: an entry's table angle is the sum of its two, as robot.py:252 forms it
   double* gl_zt = nullptr;          // [B0] measured range per beam
   double* gl_el = nullptr;          // [B0] exp(-lambda * z_meas)
   double* gl_zm = nullptr;          // [B0] staged measurement

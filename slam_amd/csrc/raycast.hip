@@ -159,7 +159,11 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (sizeo
   float* s_relx = reinterpret_cast<float*>(s_walk_all + (size_t)WPB * kWaveScratch);  // [G + B] extended angle table
   unsigned short* s_perm = reinterpret_cast<unsigned short*>(s_relx + NXP);
   unsigned short* s_lut = s_perm + B;
-  unsigned int* s_cls = reinterpret_cast<unsigned int*>(s_lut + ((NB + B + 1) & ~1) - B);   // [NE] class << 16 | beam of entry e (GRID), 4-byte aligned
+  unsigned int* s_cls = reinterpret_cast<unsigned int*>(s_lut + ((NB + B + 1) & ~1) - B);   // [NE] class << 20 | heading << 10 | beam of entry e (GRID), 4-byte aligned
+  // GRID: what the entry-by-entry test at a sector edge reads -- the entries of every class and the two terms of an entry's own angle
+  double* s_ang = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(s_cls + NE) + 7) & ~(uintptr_t)7);   // [B0] beam angles, [D] heading angles (radians)
+  unsigned short* s_member = reinterpret_cast<unsigned short*>(s_ang + (GRID ? P.g_B0 + P.g_D : 0));   // [NE] entries by class
+  unsigned short* s_first = s_member + NE;                                                     // [B + 1] start of every class in s_member
 
   for (int k = threadIdx.x; k < B; k += blockDim.x) {
     s_ts[k] = P.tab_sorted[k];
@@ -170,8 +174,11 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (sizeo
       s_zt[k] = P.zt[k];
       s_el[k] = P.etalam[k];
     }
-  if (GRID)
-    for (int k = threadIdx.x; k < NE; k += blockDim.x) s_cls[k] = P.g_cls[k];
+  if (GRID) {
+    for (int k = threadIdx.x; k < NE; k += blockDim.x) { s_cls[k] = P.g_cls[k]; s_member[k] = P.g_member[k]; }
+    for (int k = threadIdx.x; k <= B; k += blockDim.x) s_first[k] = P.g_cls_first[k];
+    for (int k = threadIdx.x; k < P.g_B0 + P.g_D; k += blockDim.x) s_ang[k] = P.g_ar[k];   // one array: beams, then headings
+  }
   for (int k = threadIdx.x; k < NXP; k += blockDim.x) s_relx[k] = (k < P.G + B) ? P.relx[k] : 1.0e30f;  // padding: beyond any window
   for (int k = threadIdx.x; k < NB; k += blockDim.x) s_lut[k] = P.lut[k];
   __syncthreads();
@@ -317,9 +324,11 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (sizeo
                   const int ke = ie - G + (ie < G ? B : 0);   // its beam, sorted order
                   if constexpr (GRID) {
                     // every entry of the class with its own angle (robot.py:252-258)
-                    for (int m = P.g_cls_first[ke]; m < P.g_cls_first[ke + 1]; ++m) {
-                      const double de = fabs((P.g_mbeta[m] + th) - a_exact);
-                      if ((de <= P.half) || (de >= P.two_pi_lo && de <= P.two_pi_hi)) atomicMin(&emin[P.g_member[m]], r2bits);
+                    for (int m = s_first[ke]; m < s_first[ke + 1]; ++m) {
+                      const unsigned int me = s_member[m], ck = s_cls[me];
+                      const double beta = s_ang[ck & 0x3ffu] + s_ang[P.g_B0 + ((ck >> 10) & 0x3ffu)];   // robot.py:252
+                      const double de = fabs((beta + th) - a_exact);
+                      if ((de <= P.half) || (de >= P.two_pi_lo && de <= P.two_pi_hi)) atomicMin(&emin[me], r2bits);
                     }
                   } else {
                     const double beta = s_ts[ke] + th;          // :143
@@ -437,12 +446,12 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (sizeo
       // common case stays free of the root / exponential / division they need
       auto own_range = [&](unsigned int k) {
         const unsigned int ck = s_cls[k];
-        const int cc = (int)(ck >> 16);
+        const int cc = (int)(ck >> 20);
         double z = __longlong_as_double((long long)rmin[G + cc]);
         double eta = etac[cc];
         const double zo = sqrt(__longlong_as_double((long long)emin[k]));
         if (zo < z) { z = zo; eta = 1.0 / (1.0 - exp(-P.lambda * z)); }
-        emin[k] = (unsigned long long)__double_as_longlong(entry_px((int)(ck & 0xffffu), z, eta));
+        emin[k] = (unsigned long long)__double_as_longlong(entry_px((int)(ck & 0x3ffu), z, eta));
       };
       int waiting = 0;
       for (int k0 = 0; k0 < NE; k0 += 64) {
@@ -450,11 +459,11 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (sizeo
         bool own = false;
         if (k < NE) {
           const unsigned int ck = s_cls[k];
-          const int cc = (int)(ck >> 16);
+          const int cc = (int)(ck >> 20);
           const double z = __longlong_as_double((long long)rmin[G + cc]);
           const unsigned long long me = emin[k];
           own = (me != r2max_bits) && (__longlong_as_double((long long)me) <= z * z * (1.0 + 1e-15));
-          if (!own) emin[k] = (unsigned long long)__double_as_longlong(entry_px((int)(ck & 0xffffu), z, etac[cc]));   // in place: the minimum is spent
+          if (!own) emin[k] = (unsigned long long)__double_as_longlong(entry_px((int)(ck & 0x3ffu), z, etac[cc]));   // in place: the minimum is spent
         }
         const unsigned long long om = __ballot(own);
         if (own) {
@@ -585,7 +594,11 @@ static size_t ray_lds_bytes(int B, int G, int NB, bool aux, int waves = kWavesPe
   s += (size_t)waves * kWaveScratch * sizeof(unsigned int);
   s += (size_t)NXP * sizeof(float);
   s += ((size_t)B + NB + 4) * sizeof(unsigned short);
-  s += (size_t)NE * sizeof(unsigned int);
+  if (NE) {
+    s += (size_t)NE * sizeof(unsigned int) + 8;                            // class / heading / beam of every entry (+ alignment of what follows)
+    s += (size_t)(B0 + NE / B0) * sizeof(double);                          // beam and heading angles
+    s += ((size_t)NE + B + 2) * sizeof(unsigned short);                    // entries by class, class starts
+  }
   return (s + 15) & ~(size_t)15;
 }
 
@@ -596,7 +609,7 @@ int launch_grid_update(mclhip_ctx* c, const double* d_x, const double* d_y, cons
   if (n <= 0) return MCLHIP_OK;
   RayParams P = make_ray_params(c);
   P.g_cell = d_cell; P.g_D = n_dir; P.g_B0 = beams_per_dir; P.g_pk_pred = pk_pred; P.g_pk = pk;
-  P.g_NE = c->gl_NE; P.g_cls = c->gl_cls; P.g_cls_first = c->gl_cls_first; P.g_member = c->gl_member; P.g_mbeta = c->gl_mbeta;
+  P.g_NE = c->gl_NE; P.g_cls = c->gl_cls; P.g_cls_first = c->gl_cls_first; P.g_member = c->gl_member; P.g_ar = c->gl_mbeta; P.g_thd = c->gl_mbeta + beams_per_dir;
   P.zt = c->gl_zt; P.etalam = c->gl_el;   // per beam of one heading
   // as many waves per block as the LDS holds: 16, 12, 8 or 4
   const size_t lds_max = 160 * 1024;
