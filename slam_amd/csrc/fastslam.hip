@@ -112,17 +112,23 @@ __device__ inline double wrap_residual(double d) {
   return d;
 }
 
-// two independent standard normals from the counter-based generator (both Box-Muller outputs of two
-// 32-bit words)
-__device__ inline void device_normal_pair(uint64_t particle, uint32_t draw, uint64_t seed, double* a, double* b) {
+// four independent standard normals from one block of the counter-based generator: two Box-Muller pairs in
+// float32 on the hardware's log2 / sqrt / sin / cos (sin and cos take their argument in turns, so the uniform
+// number goes in as it is).  The draws of a device-noise run are its own stream, not numpy's: what matters is
+// their distribution, and a 24-bit uniform with single-precision transcendentals gives a normal whose error is
+// far below the sensor noise it models.
+__device__ inline void box_muller_f32(uint32_t a, uint32_t b, double* n0, double* n1) {
+  const float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0, 1)
+  const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);            // [0, 1), in turns
+  const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1)
+  *n0 = (double)(rad * __builtin_amdgcn_cosf(u2));
+  *n1 = (double)(rad * __builtin_amdgcn_sinf(u2));
+}
+__device__ inline void device_normal_quad(uint64_t particle, uint32_t draw, uint64_t seed, double out[4]) {
   uint32_t ctr[4] = {(uint32_t)particle, (uint32_t)(particle >> 32), draw, 0x4653u};
   philox4x32(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
-  const double u1 = ((double)ctr[0] + 1.0) * (1.0 / 4294967296.0);   // (0, 1]
-  const double u2 = (double)ctr[1] * (1.0 / 4294967296.0);
-  const double rad = sqrt(-2.0 * log(u1));
-  double sn, cs;
-  sincos(2.0 * M_PI * u2, &sn, &cs);
-  *a = rad * cs; *b = rad * sn;
+  box_muller_f32(ctr[0], ctr[1], &out[0], &out[1]);
+  box_muller_f32(ctr[2], ctr[3], &out[2], &out[3]);
 }
 
 #ifndef FS_WAVES
@@ -227,26 +233,33 @@ __global__ __launch_bounds__(128) void fs_draw_kernel(const FsParams P, const do
   const int nv = P.L;
   const double* normals = P.normals ? P.normals + p * P.n_norm : nullptr;
   double mr = 0.0, mphi = 0.0;
-  for (int u = 0; u < nv; ++u) {
-    const double2 t = truth[u];
-    double n_r, n_phi;
+  for (int u0 = 0; u0 < nv; u0 += 2) {
+    double nn[4] = {0.0, 0.0, 0.0, 0.0};   // (range, bearing) noise of landmarks u0 and u0 + 1
     if (normals) {
-      n_r = normals[2 * u];
-      n_phi = normals[2 * u + 1];
+      nn[0] = normals[2 * u0]; nn[1] = normals[2 * u0 + 1];
+      if (u0 + 1 < nv) { nn[2] = normals[2 * u0 + 2]; nn[3] = normals[2 * u0 + 3]; }
     } else {
-      device_normal_pair((uint64_t)(P.index0 + p), (uint32_t)u, P.seed, &n_r, &n_phi);
+      device_normal_quad((uint64_t)(P.index0 + p), (uint32_t)(u0 >> 1), P.seed, nn);
     }
-    const double zr = t.x + n_r * P.std_r;
-    double zphi = t.y + n_phi * P.std_phi;
-    if (zphi > M_PI) zphi -= 2 * M_PI;
-    else if (zphi < -M_PI) zphi += 2 * M_PI;
-    mr = fmax(mr, fabs(n_r * P.std_r)); mphi = fmax(mphi, fabs(n_phi * P.std_phi));
-    const bool in_range = zr <= P.r_max;        // :291
-    double* m = MREC(u);
-    FLD(m, M_ZR) = in_range ? zr : __longlong_as_double(0x7ff8000000000000ll);   // NaN never passes a gate
-    FLD(m, M_ZPHI) = zphi;
-    FLD(m, M_BW) = 0.0;
-    FLD_I(m, M_BC, 0) = in_range ? -1 : -2;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int u = u0 + h;
+      if (u < nv) {
+        const double2 t = truth[u];
+        const double n_r = nn[2 * h], n_phi = nn[2 * h + 1];
+        const double zr = t.x + n_r * P.std_r;
+        double zphi = t.y + n_phi * P.std_phi;
+        if (zphi > M_PI) zphi -= 2 * M_PI;
+        else if (zphi < -M_PI) zphi += 2 * M_PI;
+        mr = fmax(mr, fabs(n_r * P.std_r)); mphi = fmax(mphi, fabs(n_phi * P.std_phi));
+        const bool in_range = zr <= P.r_max;        // :291
+        double* m = MREC(u);
+        FLD(m, M_ZR) = in_range ? zr : __longlong_as_double(0x7ff8000000000000ll);   // NaN never passes a gate
+        FLD(m, M_ZPHI) = zphi;
+        FLD(m, M_BW) = 0.0;
+        FLD_I(m, M_BC, 0) = in_range ? -1 : -2;
+      }
+    }
   }
   P.noise[p] = mr;
   P.noise[P.M + p] = mphi;

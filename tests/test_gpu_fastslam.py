@@ -190,3 +190,40 @@ def test_dense_landmark_field_against_the_oracle():
         assert np.array_equal(idx, orc.last_idx), t
         _compare(ctx.fs_get_state(), orc.state(cap), t)
     assert nv > 40 and int(ctx.fs_get_state()["nfeat"].max()) > nv
+
+
+def test_device_measurement_noise_is_standard_normal():
+    """The on-device generator of the measurement noise (float32 Box-Muller on a counter-based generator) is its
+    own stream: its contract is the distribution.  After one step from the origin every feature is a birth at
+    pose + z, so the drawn (range, bearing) noise can be read back from the state: moments, independence of the
+    two components and of neighbouring landmarks, and a Kolmogorov-Smirnov test."""
+    from scipy import stats
+    from slam_amd import _lib as L
+    M, nl = 1 << 18, 4      # few landmarks: the weight P0 ** nl of a step of births must stay above the 1e-8 floor of the sum
+    ang = np.arange(nl) * 2 * np.pi / nl + 0.3
+    lm = np.stack([6 * np.cos(ang) + 1, 6 * np.sin(ang), np.zeros(nl)], 1).astype(np.float32)
+    ctx = L.Context(0, L.F64)
+    ctx.fs_init(M, nl + 4)
+    ut = [25, 0.001]
+    x_gt = F.true_pose_step([0, 0, 0], ut)
+    tr, tp, tv = _truth(x_gt, lm)
+    assert tv.all()
+    idx = ctx.fs_step(ut[0], ut[1], F.DT, F.ALPHA, tr, tp, tv, None, None, 0.5 / M, seed=77, want_idx=True)
+    assert np.array_equal(idx, np.arange(M))            # equal weights: every particle once
+    st = ctx.fs_get_state()
+    assert np.all(st["nfeat"] == nl)
+    d = st["f_m"][:, :nl, :] - st["pose"][:, None, :2]
+    zr = np.hypot(d[..., 0], d[..., 1])
+    zphi = np.arctan2(d[..., 1], d[..., 0]) - st["pose"][:, None, 2]
+    n_r = (zr - tr[None, :]) / F.STD_R
+    n_phi = (zphi - tp[None, :] + np.pi) % (2 * np.pi) - np.pi
+    n_phi = n_phi / F.STD_PHI
+    n = n_r.size
+    for v in (n_r, n_phi):
+        assert abs(v.mean()) < 5 / np.sqrt(n) and abs(v.var() - 1) < 0.01
+        assert abs(stats.skew(v.ravel())) < 0.012 and abs(stats.kurtosis(v.ravel())) < 0.025
+        assert stats.kstest(v.ravel()[::37], "norm").pvalue > 1e-3
+        assert np.abs(v).max() < 6.7                    # sqrt(-2 ln 2^-25)
+    assert abs(np.corrcoef(n_r.ravel(), n_phi.ravel())[0, 1]) < 5 / np.sqrt(n)
+    assert abs(np.corrcoef(n_r[:, 0::2].ravel(), n_r[:, 1::2].ravel())[0, 1]) < 5 / np.sqrt(n / 2)   # same generator block
+    assert abs(np.corrcoef(n_r[:-1, 3], n_r[1:, 3])[0, 1]) < 5 / np.sqrt(M)                          # neighbouring particles
