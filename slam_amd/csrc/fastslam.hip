@@ -624,6 +624,9 @@ struct FsState {
   unsigned long long* d_sectors = nullptr;        // landmark sets per bearing sector and block of 64, then one set of all per block
   int32_t* overflow = nullptr;
   int32_t* d_maxfeat = nullptr;                   // largest feature count of a particle
+  int32_t max_feat = 0; bool max_feat_valid = false;   // its host copy; valid between the end of a step and the next step's kernels
+  std::vector<double> h_truth;                    // host sides of the per-step tables (alive while their uploads are in flight)
+  std::vector<unsigned long long> h_sect;
   int16_t* d_ints = nullptr; double* d_normals = nullptr; int64_t normals_cap = 0;
   unsigned long long* stage = nullptr; int64_t stage_words = 0;   // feature rows on their way to / from another rank
   double std_r = 0.5, std_phi = 3 * M_PI / 180.0, r_max = 10.0, p0 = 0.01, thres_sig = 2.0;
@@ -654,6 +657,17 @@ static int fs_stage(mclhip_ctx* c, FsState* s, int64_t words) {
 #define F_TRY(expr) do { int rc__ = (expr); if (rc__ != MCLHIP_OK) return rc__; } while (0)
 #define F_HIP(expr) MCL_HIP(c, expr)
 
+// enqueues the count of the largest feature list; s->max_feat holds it once the stream has been synchronised
+static int fs_count_features(mclhip_ctx* c, FsState* s, const int32_t* nfeat) {
+  F_HIP(hipMemsetAsync(s->d_maxfeat, 0, sizeof(int32_t), c->stream));
+  hipLaunchKernelGGL(fs_max_count_kernel, dim3((unsigned)std::min<int64_t>((s->M + 255) / 256, 256)), dim3(256), 0, c->stream,
+                     nfeat, s->M, s->d_maxfeat);
+  F_HIP(hipGetLastError());
+  F_HIP(hipMemcpyAsync(&s->max_feat, s->d_maxfeat, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  s->max_feat_valid = true;
+  return MCLHIP_OK;
+}
+
 // uploads the step's inputs and enqueues the per-particle kernels (pose sample .. weight / decay pass)
 static int fs_enqueue_kernel(mclhip_ctx* c, double v, double omega, double dt, const double alpha[6], const double* truth_r,
                              const double* truth_phi, const uint8_t* truth_valid, int L, const int16_t* ints,
@@ -667,7 +681,8 @@ static int fs_enqueue_kernel(mclhip_ctx* c, double v, double omega, double dt, c
   // landmarks in range of the true pose, in landmark order, as (r, phi) pairs: measure() returns
   // r_max + 1 for the others, which fast_slam() skips (:291).  Padded to a multiple of eight with readings
   // no feature is near.
-  std::vector<double> near;
+  std::vector<double>& near = s->h_truth;
+  near.clear();
   for (int l = 0; l < L; ++l)
     if (truth_valid[l]) { near.push_back(truth_r[l]); near.push_back(truth_phi[l]); }
   const int n_valid = (int)(near.size() / 2);
@@ -687,7 +702,8 @@ static int fs_enqueue_kernel(mclhip_ctx* c, double v, double omega, double dt, c
   const int n_blk = (n_valid + 63) / 64;
   if (!near.empty()) {
     // the association sweep's index: which landmarks of every block of 64 have their bearing in which sector of the circle
-    std::vector<unsigned long long> sect((size_t)n_blk * (kSectors + 1), 0ull);
+    std::vector<unsigned long long>& sect = s->h_sect;
+    sect.assign((size_t)n_blk * (kSectors + 1), 0ull);
     for (int u = 0; u < n_valid; ++u) {
       const double phi = near[2 * u + 1];
       const unsigned long long bit = 1ull << (u & 63);
@@ -701,7 +717,6 @@ static int fs_enqueue_kernel(mclhip_ctx* c, double v, double omega, double dt, c
     }
     F_HIP(hipMemcpyAsync(s->d_truth, near.data(), near.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     F_HIP(hipMemcpyAsync(s->d_sectors, sect.data(), sect.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
-    F_HIP(hipStreamSynchronize(c->stream));   // the tables are locals
   }
   if (ints) {
     if (!s->d_ints) F_HIP(hipMalloc((void**)&s->d_ints, (size_t)M * 36 * sizeof(int16_t)));
@@ -717,12 +732,14 @@ static int fs_enqueue_kernel(mclhip_ctx* c, double v, double omega, double dt, c
     F_HIP(hipMemcpyAsync(s->d_normals, normals, (size_t)need * sizeof(double), hipMemcpyHostToDevice, c->stream));
   }
   const int a = s->cur;
-  // rows of the update sweep's LDS table: the largest feature count any particle holds
-  int32_t max_feat = 0;
-  F_HIP(hipMemsetAsync(s->d_maxfeat, 0, sizeof(int32_t), c->stream));
-  hipLaunchKernelGGL(fs_max_count_kernel, dim3((unsigned)std::min<int64_t>((M + 255) / 256, 256)), dim3(256), 0, c->stream, s->nfeat[a], M, s->d_maxfeat);
-  F_HIP(hipMemcpyAsync(&max_feat, s->d_maxfeat, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-  F_HIP(hipStreamSynchronize(c->stream));
+  // rows of the update sweep's LDS table: the largest feature count any particle holds (left by the end of the
+  // previous step; counted now if this is not the call that follows one)
+  if (!s->max_feat_valid) {
+    F_TRY(fs_count_features(c, s, s->nfeat[a]));
+    F_HIP(hipStreamSynchronize(c->stream));
+  }
+  const int32_t max_feat = s->max_feat;
+  s->max_feat_valid = false;                       // births of this step may raise it
   FsParams P;
   P.M = M; P.F = s->F; P.L = n_valid; P.mcap = s->mcap;
   P.v = v; P.w = omega; P.dt = dt;
@@ -829,6 +846,7 @@ int mclhip_fs_step(mclhip_ctx* c, double v, double omega, double dt, const doubl
                      s->nfeat[b], s->newid[b], (const double*)s->feat[a], s->feat[b]);
   F_HIP(hipGetLastError());
   s->cur = b;
+  F_TRY(fs_count_features(c, s, s->nfeat[b]));
   int32_t ov = 0;
   F_HIP(hipMemcpyAsync(&ov, s->overflow, sizeof(ov), hipMemcpyDeviceToHost, c->stream));
   F_HIP(hipStreamSynchronize(c->stream));
@@ -942,6 +960,7 @@ int mclhip_fs_shard_unpack(mclhip_ctx* c, const void* rows, int64_t L, int64_t r
   hipLaunchKernelGGL(fs_unpack_rows_kernel, dim3((unsigned)((s->M + 63) / 64), s->F + 1), dim3(64), 0, c->stream, c->idx,
                      row0_global, L, s->M, s->F, (const unsigned long long*)s->stage, s->nfeat[b], s->newid[b], s->feat[b]);
   F_HIP(hipGetLastError());
+  F_TRY(fs_count_features(c, s, s->nfeat[b]));
   F_HIP(hipStreamSynchronize(c->stream));
   s->cur = b;
   return MCLHIP_OK;
