@@ -227,3 +227,31 @@ def test_device_measurement_noise_is_standard_normal():
     assert abs(np.corrcoef(n_r.ravel(), n_phi.ravel())[0, 1]) < 5 / np.sqrt(n)
     assert abs(np.corrcoef(n_r[:, 0::2].ravel(), n_r[:, 1::2].ravel())[0, 1]) < 5 / np.sqrt(n / 2)   # same generator block
     assert abs(np.corrcoef(n_r[:-1, 3], n_r[1:, 3])[0, 1]) < 5 / np.sqrt(M)                          # neighbouring particles
+
+
+def test_many_landmarks_in_range_and_none():
+    """More than 254 landmarks in range (two-byte entries in the update sweep's table, five blocks of 64 in the
+    association index), a ragged particle count, and a step in which nothing is in range."""
+    from slam_amd import _lib as L
+    M, nl, cap = 70, 300, 340
+    rng = np.random.RandomState(4)
+    rad, ang = rng.uniform(1.5, 7.0, nl), rng.uniform(-np.pi, np.pi, nl)
+    lm = np.stack([rad * np.cos(ang) + 0.5, rad * np.sin(ang), np.zeros(nl)], 1).astype(np.float32)
+    ctx = L.Context(0, L.F64)
+    ctx.fs_init(M, cap)
+    orc = F.OracleFastSLAM(M, lm)
+    x_gt = [0, 0, 0]
+    seen = []
+    for t, ut in enumerate([[8.0, 0.3], [8.0, -0.4], [4000.0, 0.001], [8.0, 0.3]]):   # the third step leaves the field
+        x_gt = F.true_pose_step(x_gt, ut)
+        tr, tp, tv = _truth(x_gt, lm)
+        nv = int(tv.sum())
+        seen.append(nv)
+        ints = rng.randint(-1000, 1000, size=(M, 3, 12)).astype(np.int16)
+        normals = rng.randn(M, 2 * nv)
+        ru = float(rng.rand())
+        idx = ctx.fs_step(ut[0], ut[1], F.DT, F.ALPHA, tr, tp, tv, ints, normals, ru / M, want_idx=True)
+        orc.step(ut, ints, normals, ru)
+        assert np.array_equal(idx, orc.last_idx), t
+        _compare(ctx.fs_get_state(), orc.state(cap), t)
+    assert max(seen) >= 255 and min(seen) == 0, seen
