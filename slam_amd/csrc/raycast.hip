@@ -648,26 +648,30 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
   P.range_noise = range_noise;
   const bool stage = ranges_out != nullptr;
   const size_t lds = ray_lds_bytes(P.B, P.G, P.NB, stage || product);
-  if (lds > 64 * 1024) return fail(c, MCLHIP_E_LIMIT, "beam table does not fit the kernel's LDS budget");
+  if (lds > 160 * 1024) return fail(c, MCLHIP_E_LIMIT, "beam table does not fit the kernel's LDS budget");
   int64_t blocks = (n + kWavesPerBlock - 1) / kWavesPerBlock;
   const int64_t max_blocks = 256 * 8 * 4;   // 8192 blocks of four waves; each wave loops over particles
   if (blocks > max_blocks) blocks = max_blocks;
   dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
+  // large beam tables need more dynamic LDS than a kernel gets by default
+#define MCL_RAY(TT, SS, PP)                                                                                          \
+  do {                                                                                                               \
+    auto kern = raycast_kernel<TT, SS, PP>;                                                                          \
+    if (lds > 48 * 1024)                                                                                             \
+      MCL_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                     (int)lds));                                                                     \
+    hipLaunchKernelGGL(kern, grid, block, lds, c->stream, P, (const TT*)x, (const TT*)y, (const TT*)th, pm, n, w_out, \
+                       logw_out, ranges_out, hits_out);                                                              \
+  } while (0)
   if (stage) {
     if (dtype != MCLHIP_F64) return fail(c, MCLHIP_E_ARG, "stage query takes float64 poses");
-    hipLaunchKernelGGL((raycast_kernel<double, true, false>), grid, block, lds, c->stream, P, (const double*)x,
-                       (const double*)y, (const double*)th, pm, n, w_out, logw_out, ranges_out, hits_out);
+    MCL_RAY(double, true, false);
+  } else if (dtype == MCLHIP_F32) {
+    if (product) MCL_RAY(float, false, true); else MCL_RAY(float, false, false);
   } else {
-#define MCL_RAY(TT, PP)                                                                                         \
-  hipLaunchKernelGGL((raycast_kernel<TT, false, PP>), grid, block, lds, c->stream, P, (const TT*)x, (const TT*)y, \
-                     (const TT*)th, pm, n, w_out, logw_out, ranges_out, hits_out)
-    if (dtype == MCLHIP_F32) {
-      if (product) MCL_RAY(float, true); else MCL_RAY(float, false);
-    } else {
-      if (product) MCL_RAY(double, true); else MCL_RAY(double, false);
-    }
-#undef MCL_RAY
+    if (product) MCL_RAY(double, false, true); else MCL_RAY(double, false, false);
   }
+#undef MCL_RAY
   MCL_HIP(c, hipGetLastError());
   return MCLHIP_OK;
 }

@@ -364,3 +364,44 @@ def test_device_side_initialisation_has_the_reference_distribution():
     mcl.sample([1.5, 0], 0.1)
     mcl.resample()
     assert np.isfinite(mcl.w).all()
+
+
+def test_limits_and_smallest_sizes():
+    """The largest beam table (1024), one beam, one particle, a one-cell map; sizes beyond the limits are refused."""
+    L = _lib()
+    rng = np.random.RandomState(3)
+    grid = np.full((48, 64), 255, np.uint8)
+    grid[rng.randint(0, 48, 150), rng.randint(0, 64, 150)] = 0
+    lut, cell = O.obstacle_lut(grid)
+    poses = np.stack([rng.uniform(0, 9.6, 6), rng.uniform(0, 7.2, 6), rng.uniform(-4, 4, 6)], 1)
+    for B in (1024, 1, 7):
+        angles = [k * 360.0 / B for k in range(B)]
+        ctx = L.Context(0, L.F64)
+        ctx.set_map(grid, O.RES_X, O.RES_Y)
+        _sensor(ctx, angles)
+        R, Hc = ctx.raycast(poses)
+        Ro, Ho = O.sector_query_batch(poses, lut, cell, angles)
+        assert np.array_equal(R, Ro) and np.array_equal(Hc.astype(np.int64), Ho), B
+        # one particle through the whole update
+        ctx.set_particles(poses[:1])
+        noise = rng.randint(-1000, 1001, size=(1, 3, 12)).astype(np.int16)
+        ctx.sample(1.5, 0.5, 0.1, ALPHA, R[1], noise)
+        Xo, pmo = O.motion(poses[:1], (1.5, 0.5), 0.1, grid, noise)
+        X, w, logw = ctx.get_particles(True, True, True)
+        assert rel_err(X, Xo) < 1e-12
+        total = ctx.normalise(0)
+        assert total == np.sum(w)
+        assert np.array_equal(ctx.resample(0.25), [0])
+        ctx.close()
+    ctx = L.Context(0, L.F64)
+    with pytest.raises(L.MclHipError):
+        _sensor(ctx, [k * 360.0 / 1025 for k in range(1025)])
+    with pytest.raises(L.MclHipError):
+        ctx.raycast(poses)                                  # nothing set yet
+    one = np.zeros((1, 1), np.uint8)
+    ctx.set_map(one, O.RES_X, O.RES_Y)
+    _sensor(ctx, [0.0, 90.0, 180.0])
+    R, Hc = ctx.raycast(np.array([[1.0, 0.0, 0.0], [0.0, 0.0, 0.0]]))
+    Ro, Ho = O.sector_query_batch(np.array([[1.0, 0.0, 0.0], [0.0, 0.0, 0.0]]), *O.obstacle_lut(one), [0.0, 90.0, 180.0])
+    assert np.array_equal(R, Ro) and np.array_equal(Hc.astype(np.int64), Ho)
+    ctx.close()
