@@ -208,3 +208,31 @@ def test_full_size_properties():
     ctx.grid_predict(1.5, 0.5, G.DT, ALPHA)
     b = ctx.grid_get_belief(False, True)[1][512:520, 512:520]
     assert np.allclose(b, 0.5 * a, rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("n_dir,n_beams", [(64, 16), (1, 1), (128, 8)])
+def test_table_limits(n_dir, n_beams):
+    """The largest (heading, beam) table the update takes -- 1024 entries, as 64 x 16 and as 128 x 8 -- and the
+    smallest; one entry more is refused."""
+    from slam_amd import _lib as L
+    n = 16
+    grid = _small_map(n, n_dir)
+    res_theta = 360.0 / n_dir
+    angles = [k * 360.0 / n_beams + 1.3 for k in range(n_beams)]
+    ctx = _ctx(grid, n_dir, res_theta, angles)
+    rng = np.random.RandomState(n_dir)
+    pred = rng.rand(n, n, n_dir) ** 2
+    pred[grid < 200] = 0
+    z_meas = list(rng.uniform(0.2, 5.0, n_beams))
+    ii, jj, Z = G.predicted_ranges(grid, n_dir, angles=angles, res_theta=res_theta)
+    want, total, _ = G.update(pred, grid, z_meas, n_dir, angles=angles, Z=Z)
+    ctx.grid_set_prediction(pred)
+    got_total = ctx.grid_update(z_meas)
+    got = ctx.grid_get_belief()[0]
+    assert got_total == total
+    assert np.array_equal(got, want), "%d cells differ" % np.sum(got != want)
+    if n_dir == 64:
+        sp = O.SensorParams()
+        with pytest.raises(L.MclHipError):
+            ctx.grid_set_sensor(angles + [359.0], n_dir, res_theta, sp.z_max, sp.sigma_hit, sp.lambda_short,
+                                [sp.w_hit, sp.w_short, sp.w_max, sp.w_rand], HALF)

@@ -405,3 +405,32 @@ def test_limits_and_smallest_sizes():
     Ro, Ho = O.sector_query_batch(np.array([[1.0, 0.0, 0.0], [0.0, 0.0, 0.0]]), *O.obstacle_lut(one), [0.0, 90.0, 180.0])
     assert np.array_equal(R, Ro) and np.array_equal(Hc.astype(np.int64), Ho)
     ctx.close()
+
+
+def test_widest_map():
+    """A map as wide as the kernels take (65535 cells; cell coordinates are packed in 16 bits): obstacles and poses
+    at the far end, where the float32 cell coordinates have lost most of their fraction bits."""
+    L = _lib()
+    H, W = 12, 65535
+    grid = np.full((H, W), 255, np.uint8)
+    rng = np.random.RandomState(8)
+    cols = np.concatenate([rng.randint(W - 80, W, 60), rng.randint(32700, 32840, 60), rng.randint(0, 60, 30)])
+    grid[rng.randint(0, H, len(cols)), cols] = 0
+    lut, cell = O.obstacle_lut(grid)
+    angles = [0, 15, 30, 45, 60, 75, 90, 345, 330, 315, 300, 285, 270]
+    ctx = L.Context(0, L.F64)
+    ctx.set_map(grid, O.RES_X, O.RES_Y)
+    _sensor(ctx, angles)
+    xs = np.concatenate([rng.uniform((W - 90) * 0.15, (W + 5) * 0.15, 40), rng.uniform(32690 * 0.15, 32850 * 0.15, 40),
+                         rng.uniform(-1, 10, 20)])
+    poses = np.stack([xs, rng.uniform(-0.5, H * 0.15 + 0.5, len(xs)), rng.uniform(-7, 7, len(xs))], 1)
+    R, Hc = ctx.raycast(poses)
+    Ro, Ho = O.sector_query_batch(poses, lut, cell, angles)
+    assert np.array_equal(R, Ro) and np.array_equal(Hc.astype(np.int64), Ho)
+    assert np.any(R < 5.0)
+    X, pm = ctx.motion(poses, 1.5, 0.5, 0.1, ALPHA, None)
+    Xo, pmo = O.motion(poses, (1.5, 0.5), 0.1, grid, None)
+    assert rel_err(X, Xo) < 1e-12 and np.array_equal(pm, pmo)
+    with pytest.raises(L.MclHipError):
+        ctx.set_map(np.full((2, 65536), 255, np.uint8), O.RES_X, O.RES_Y)
+    ctx.close()
