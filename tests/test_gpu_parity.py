@@ -434,3 +434,32 @@ def test_widest_map():
     with pytest.raises(L.MclHipError):
         ctx.set_map(np.full((2, 65536), 255, np.uint8), O.RES_X, O.RES_Y)
     ctx.close()
+
+
+@pytest.mark.parametrize("res,z_max,half_deg,angles", [
+    ((0.02, 0.02), 5.0, 5.0, [0, 15, 30, 45, 60, 75, 90, 345, 330, 315, 300, 285, 270]),      # 250 cells of reach
+    ((0.15, 0.4), 5.0, 5.0, [0, 90, 180, 270, 10, 20]),                                       # oblong cells
+    ((0.15, 0.15), 3.0, 1.0, [k * 360.0 / 50 for k in range(50)]),                            # narrow sectors
+    ((0.15, 0.15), 5.0, 30.0, [0, 15, 30, 45, 60, 75, 90, 345, 330, 315, 300, 285, 270]),     # overlapping wide sectors
+    ((0.15, 0.15), 5.0, 5.0, [0, 0, 90, 90.0, -30, 400, 720, -359.5, 359.5, 180, 180]),       # repeated and unreduced angles
+])
+def test_sector_query_other_geometries(res, z_max, half_deg, angles):
+    L = _lib()
+    rng = np.random.RandomState(int(half_deg * 10 + len(angles)))
+    n = 300 if res[0] < 0.1 else 70
+    grid = np.full((n, n), 255, np.uint8)
+    grid[rng.randint(0, n, 3 * n), rng.randint(0, n, 3 * n)] = 0
+    lut, cell = O.obstacle_lut(grid, res[0], res[1])
+    sp = O.SensorParams(z_max=z_max)
+    half = half_deg * np.pi / 180.0
+    ctx = L.Context(0, L.F64)
+    ctx.set_map(grid, res[0], res[1])
+    ctx.set_sensor(angles, sp.z_max, sp.sigma_hit, sp.lambda_short, [sp.w_hit, sp.w_short, sp.w_max, sp.w_rand], half)
+    poses = np.stack([rng.uniform(-0.5, n * res[0] + 0.5, 120), rng.uniform(-0.5, n * res[1] + 0.5, 120),
+                      rng.uniform(-7, 7, 120)], 1)
+    R, Hc = ctx.raycast(poses)
+    Ro, Ho = O.sector_query_batch(poses, lut, cell, angles, z_max=z_max, half_angle=half)
+    assert np.array_equal(R, Ro), int(np.sum(R != Ro))
+    assert np.array_equal(Hc.astype(np.int64), Ho)
+    assert np.any(R < z_max) and np.any(R == z_max)
+    ctx.close()
