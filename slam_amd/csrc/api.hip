@@ -222,7 +222,15 @@ static int enqueue_sample(mclhip_ctx* c, double v, double omega, double dt, cons
 
 static int upload_zmeas(mclhip_ctx* c, const double* z_meas) {
   if (!z_meas) return fail(c, MCLHIP_E_ARG, "z_meas is NULL");
-  MCL_HIP(c, hipMemcpyAsync(c->zmeas_stage, z_meas, c->B * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  const int k = c->zslot;
+  c->zslot = (c->zslot + 1) % mclhip_ctx::kZSlots;
+  if (!c->zev[k]) MCL_HIP(c, hipEventCreateWithFlags(&c->zev[k], hipEventDisableTiming));
+  if (c->zev_set[k]) MCL_HIP(c, hipEventSynchronize(c->zev[k]));   // the slot's previous upload
+  double* host = c->zpin + (size_t)k * c->B;
+  std::memcpy(host, z_meas, c->B * sizeof(double));
+  MCL_HIP(c, hipMemcpyAsync(c->zmeas_stage, host, c->B * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  MCL_HIP(c, hipEventRecord(c->zev[k], c->stream));
+  c->zev_set[k] = true;
   return MCLHIP_OK;
 }
 
@@ -287,6 +295,9 @@ void mclhip_destroy(mclhip_ctx* c) {
                   c->rows_send, c->rows_recv, c->small_d, c->small_i};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (c->zpin) (void)hipHostFree(c->zpin);
+  for (int k = 0; k < mclhip_ctx::kZSlots; ++k)
+    if (c->zev[k]) (void)hipEventDestroy(c->zev[k]);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -404,6 +415,10 @@ int mcl::set_sensor_table(mclhip_ctx* c, const double* tab_rad, int B, double z_
   MCL_TRY(dev_alloc(c, &c->zt, B * sizeof(double)));
   MCL_TRY(dev_alloc(c, &c->etalam, B * sizeof(double)));
   MCL_TRY(dev_alloc(c, &c->zmeas_stage, B * sizeof(double)));
+  for (int k = 0; k < mclhip_ctx::kZSlots; ++k)
+    if (c->zev_set[k]) { MCL_HIP(c, hipEventSynchronize(c->zev[k])); c->zev_set[k] = false; }
+  if (c->zpin) { (void)hipHostFree(c->zpin); c->zpin = nullptr; }
+  MCL_HIP(c, hipHostMalloc((void**)&c->zpin, (size_t)mclhip_ctx::kZSlots * B * sizeof(double), hipHostMallocDefault));
   MCL_HIP(c, hipMemcpy(c->tab_sorted, ts.data(), B * sizeof(double), hipMemcpyHostToDevice));
   MCL_HIP(c, hipMemcpy(c->tab_orig, tab.data(), B * sizeof(double), hipMemcpyHostToDevice));
   MCL_HIP(c, hipMemcpy(c->perm, perm.data(), B * sizeof(uint16_t), hipMemcpyHostToDevice));
@@ -750,14 +765,9 @@ int mclhip_snapshot_particles(mclhip_ctx* c) {
 int mclhip_restore_particles_async(mclhip_ctx* c) {
   MCL_TRY(use(c));
   if (c->sM == 0 || c->sM != c->M) return fail(c, MCLHIP_E_STATE, "no snapshot of the current particle count");
-  const size_t es = esize(c);
   const int64_t M = c->M;
   const int a = c->cur;
-  MCL_HIP(c, hipMemcpyAsync(c->px[a], c->sx, M * es, hipMemcpyDeviceToDevice, c->stream));
-  MCL_HIP(c, hipMemcpyAsync(c->py[a], c->sy, M * es, hipMemcpyDeviceToDevice, c->stream));
-  MCL_HIP(c, hipMemcpyAsync(c->pth[a], c->sth, M * es, hipMemcpyDeviceToDevice, c->stream));
-  MCL_HIP(c, hipMemcpyAsync(c->w[a], c->sw, M * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-  return MCLHIP_OK;
+  return launch_restore(c, c->px[a], c->py[a], c->pth[a], c->w[a], c->sx, c->sy, c->sth, c->sw, M, c->dtype);
 }
 
 // ---- one filter over several GPUs ----------------------------------------------------------

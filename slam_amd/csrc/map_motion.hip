@@ -2,6 +2,8 @@
 // the stand-alone beam-mixture kernel.  Compiled with -ffp-contract=off: every
 // float64 expression below is meant to round exactly where the reference's
 // numpy/Python expression rounds.
+#include <algorithm>
+
 #include "mclhip_internal.h"
 #include "device_rng.h"
 
@@ -257,6 +259,31 @@ int launch_init_particles(mclhip_ctx* c, void* x, void* y, void* th, int64_t n, 
     hipLaunchKernelGGL(init_particles_kernel<float>, grid, block, 0, c->stream, (float*)x, (float*)y, (float*)th, n, mp, ip, d_failures);
   else
     hipLaunchKernelGGL(init_particles_kernel<double>, grid, block, 0, c->stream, (double*)x, (double*)y, (double*)th, n, mp, ip, d_failures);
+  MCL_HIP(c, hipGetLastError());
+  return MCLHIP_OK;
+}
+
+// the particle set re-loaded from its snapshot: three state arrays and the weights in one launch
+template <typename T>
+__global__ __launch_bounds__(256) void restore_kernel(T* __restrict__ x, T* __restrict__ y, T* __restrict__ th,
+                                                      double* __restrict__ w, const T* __restrict__ sx,
+                                                      const T* __restrict__ sy, const T* __restrict__ sth,
+                                                      const double* __restrict__ sw, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    x[i] = sx[i]; y[i] = sy[i]; th[i] = sth[i]; w[i] = sw[i];
+  }
+}
+
+int launch_restore(mclhip_ctx* c, void* x, void* y, void* th, double* w, const void* sx, const void* sy, const void* sth,
+                   const double* sw, int64_t n, int dtype) {
+  if (n <= 0) return MCLHIP_OK;
+  dim3 grid((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), block(256);
+  if (dtype == MCLHIP_F32)
+    hipLaunchKernelGGL(restore_kernel<float>, grid, block, 0, c->stream, (float*)x, (float*)y, (float*)th, w, (const float*)sx,
+                       (const float*)sy, (const float*)sth, sw, n);
+  else
+    hipLaunchKernelGGL(restore_kernel<double>, grid, block, 0, c->stream, (double*)x, (double*)y, (double*)th, w,
+                       (const double*)sx, (const double*)sy, (const double*)sth, sw, n);
   MCL_HIP(c, hipGetLastError());
   return MCLHIP_OK;
 }

@@ -112,6 +112,13 @@ struct mclhip_ctx {
   double* zt = nullptr;      // [B]
   double* etalam = nullptr;  // [B]
   double* zmeas_stage = nullptr;  // [B] staging for z_meas uploads
+  // page-locked copies of the caller's z_meas: a step that only enqueues must not leave the device reading the
+  // caller's buffer after the call has returned.  kZSlots steps may be in flight before a slot is waited for.
+  static constexpr int kZSlots = 8;
+  double* zpin = nullptr;         // [kZSlots][B], host
+  hipEvent_t zev[kZSlots] = {};   // upload of the slot has finished
+  bool zev_set[kZSlots] = {};
+  int zslot = 0;
   uint16_t* ring = nullptr;       // tile visiting order of the sector query
   int n_ring = 0;
   bool ring_dirty = true;         // map resolution or z_max changed since the table was built
@@ -213,6 +220,8 @@ int launch_nbr_count(mclhip_ctx* c, uint32_t* d_cnt);
 int launch_nbr_fill(mclhip_ctx* c);
 int launch_motion(mclhip_ctx* c, void* x, void* y, void* th, uint8_t* pm, int64_t n, const MotionParams& mp,
                   const int16_t* d_noise, int dtype);
+int launch_restore(mclhip_ctx* c, void* x, void* y, void* th, double* w, const void* sx, const void* sy, const void* sth,
+                   const double* sw, int64_t n, int dtype);
 int launch_init_particles(mclhip_ctx* c, void* x, void* y, void* th, int64_t n, const MotionParams& mp, int gaussian,
                           double ext_x, double ext_y, const double* x0, uint64_t seed, uint32_t* d_failures);
 int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, const uint8_t* pm, int64_t n,
