@@ -907,7 +907,11 @@ int mclhip_dshard_sample_max(mclhip_ctx* c, double v, double omega, double dt, c
   MCL_TRY(need(c, true, true, true));
   if (!alpha || !d_max_out) return fail(c, MCLHIP_E_ARG, "alpha or d_max_out is NULL");
   MCL_TRY(upload_zmeas(c, z_meas));
-  if (noise_ints) MCL_TRY(upload_noise(c, noise_ints));
+  if (noise_ints) {
+    // pre-drawn integers (parity runs) are read from the caller's buffer: this call returns only when that is done
+    MCL_TRY(upload_noise(c, noise_ints));
+    MCL_HIP(c, hipStreamSynchronize(c->stream));
+  }
   MCL_TRY(enqueue_sample(c, v, omega, dt, alpha, noise_ints ? 1 : 2, seed, c->spans, weight_mode == MCLHIP_W_PRODUCT));
   span_begin(c, c->spans, 2);
   MCL_TRY(launch_shard_max_logw(c));
