@@ -182,6 +182,18 @@ int mclhip_sample_augmented(mclhip_ctx* ctx, double v, double omega, double dt, 
 int mclhip_resample_augmented(mclhip_ctx* ctx, double r, const int64_t* inj_rows, const double* inj_poses,
                               int64_t n_inj, int64_t* idx_out);
 
+/* The two calls above for particle counts at which the host cannot draw the numbers (one normal per particle
+ * and beam): the motion integers (uniform on [-1000, 1000), as np.random.randint(-1000, 1000, 12) gives them,
+ * mc_localization2.py:23), the range noise range_sigma * N(0, 1) (0.15 in the reference, :166) and the
+ * injection draws (:266-283: one uniform per position, injected when <= p_random; pose uniform over
+ * [0, extent_x) x [0, extent_y) on a cell of value 255, heading U[0, 2pi)) come from the counter-based
+ * generator keyed by the global particle index and `seed`.  Same distributions as the reference, not numpy's
+ * stream.  n_injected_out (nullable): number of injected positions. */
+int mclhip_sample_augmented_device(mclhip_ctx* ctx, double v, double omega, double dt, const double alpha[6],
+                                   uint64_t seed, const double* z_meas, double range_sigma, double* w_avg_out);
+int mclhip_resample_augmented_device(mclhip_ctx* ctx, double r, double p_random, double extent_x, double extent_y,
+                                     uint64_t seed, int64_t* n_injected_out);
+
 /* Re-load the particle set from a device-resident snapshot taken by
  * mclhip_snapshot_particles (benchmark helper: every timed step starts from
  * the same synthetic cloud; a device-to-device copy, no host traffic). */

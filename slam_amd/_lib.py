@@ -55,6 +55,10 @@ PROTOTYPES = {
     "mclhip_sample_augmented": (C.c_int, [_ctx_p, C.c_double, C.c_double, C.c_double, _dbl_p, _i16_p, C.c_uint64,
                                           _dbl_p, _dbl_p, _dbl_p]),
     "mclhip_resample_augmented": (C.c_int, [_ctx_p, C.c_double, _i64_p, _dbl_p, C.c_int64, _i64_p]),
+    "mclhip_sample_augmented_device": (C.c_int, [_ctx_p, C.c_double, C.c_double, C.c_double, _dbl_p, C.c_uint64, _dbl_p,
+                                                 C.c_double, _dbl_p]),
+    "mclhip_resample_augmented_device": (C.c_int, [_ctx_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint64,
+                                                   _i64_p]),
     "mclhip_sync": (C.c_int, [_ctx_p]),
     "mclhip_snapshot_particles": (C.c_int, [_ctx_p]),
     "mclhip_restore_particles_async": (C.c_int, [_ctx_p]),
@@ -287,6 +291,24 @@ class Context:
                                                     _p(poses, _dbl_p) if len(rows) else None, len(rows),
                                                     _p(idx, _i64_p)), "mclhip_resample_augmented")
         return idx
+
+    def sample_augmented_device(self, v, omega, dt, alpha, z_meas, seed, range_sigma=0.15):
+        """Augmented-MCL sample with motion integers and range noise drawn on the device; returns w_avg."""
+        al = _f64(alpha, (6,))
+        zm = _f64(z_meas, (self.B,))
+        w_avg = C.c_double(0.0)
+        self._ck(self.lib.mclhip_sample_augmented_device(self.h, float(v), float(omega), float(dt), _p(al, _dbl_p),
+                                                         int(seed), _p(zm, _dbl_p), float(range_sigma), C.byref(w_avg)),
+                 "mclhip_sample_augmented_device")
+        return w_avg.value
+
+    def resample_augmented_device(self, r, p_random, extent_x, extent_y, seed):
+        """Augmented-MCL resampling with the injections drawn on the device; returns their number."""
+        n = C.c_int64(0)
+        self._ck(self.lib.mclhip_resample_augmented_device(self.h, float(r), float(p_random), float(extent_x),
+                                                           float(extent_y), int(seed), C.byref(n)),
+                 "mclhip_resample_augmented_device")
+        return n.value
 
     def normalise(self, mode=W_PRODUCT):
         s = C.c_double(0.0)

@@ -46,6 +46,7 @@ RayParams make_ray_params(const mclhip_ctx* c) {
   P.w_hit = c->w4[0]; P.w_short = c->w4[1]; P.w_max = c->w4[2]; P.w_rand = c->w4[3];
   P.p_rand = 1 / c->z_max;                               // range_sensor.py:64
   P.range_noise = nullptr;
+  P.rn_sigma = 0.0; P.rn_seed = 0; P.rn_index0 = c->first_index;
   P.stamps = c->stamps;
   P.g_cell = nullptr; P.g_pk_pred = nullptr; P.g_pk = nullptr; P.g_D = 0; P.g_B0 = 0;
   P.g_NE = 0; P.g_cls = nullptr; P.g_cls_first = nullptr; P.g_member = nullptr; P.g_ar = nullptr; P.g_thd = nullptr;
@@ -188,6 +189,7 @@ static MotionParams make_motion_params(const mclhip_ctx* c, double v, double ome
   mp.freeb = c->freeb;
   mp.TW = c->TW; mp.TH = c->TH; mp.W = c->W; mp.H = c->H;
   mp.noise_mode = noise_mode;
+  mp.ints_span = 2001;   // np.random.random_integers(-1000, 1000) (mc_localization.py:23)
   mp.book = 0;
   mp.seed = seed;
   mp.index0 = c->first_index;
@@ -205,9 +207,10 @@ static int need(mclhip_ctx* c, bool map, bool sensor, bool particles) {
 // enqueue motion + sector query + likelihood for the live particle set
 static int enqueue_sample(mclhip_ctx* c, double v, double omega, double dt, const double* alpha, int noise_mode,
                           uint64_t seed, std::vector<mclhip_ctx::Span>& spans, bool want_product,
-                          const double* d_range_noise = nullptr) {
+                          const double* d_range_noise = nullptr, double rn_sigma = 0.0, uint32_t ints_span = 2001) {
   MCL_TRY(launch_beam_table(c));
   MotionParams mp = make_motion_params(c, v, omega, dt, alpha, noise_mode, seed);
+  mp.ints_span = ints_span;
   const int a = c->cur;
   span_begin(c, spans, 1);
   MCL_TRY(launch_motion(c, c->px[a], c->py[a], c->pth[a], c->pm, c->M, mp, c->noise, c->dtype));
@@ -215,7 +218,7 @@ static int enqueue_sample(mclhip_ctx* c, double v, double omega, double dt, cons
   span_begin(c, spans, 0);
   // the raw product is only formed when somebody will read it: it costs one dependent multiply per beam
   MCL_TRY(launch_raycast(c, c->px[a], c->py[a], c->pth[a], c->pm, c->M, c->dtype, want_product ? c->w[a] : nullptr,
-                         c->logw, nullptr, nullptr, d_range_noise));
+                         c->logw, nullptr, nullptr, d_range_noise, rn_sigma, seed));
   span_end(c, spans);
   return MCLHIP_OK;
 }
@@ -673,6 +676,45 @@ int mclhip_resample_augmented(mclhip_ctx* c, double r, const int64_t* inj_rows, 
   MCL_TRY(launch_inject(c, c->inj_rows, c->inj_poses, n_inj, c->cur, true));
   MCL_HIP(c, hipStreamSynchronize(c->stream));
   if (idx_out) MCL_HIP(c, hipMemcpy(idx_out, c->idx, c->M * sizeof(int64_t), hipMemcpyDeviceToHost));
+  return MCLHIP_OK;
+}
+
+int mclhip_sample_augmented_device(mclhip_ctx* c, double v, double omega, double dt, const double alpha[6], uint64_t seed,
+                                   const double* z_meas, double range_sigma, double* w_avg_out) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, true, true, true));
+  if (!alpha) return fail(c, MCLHIP_E_ARG, "alpha is NULL");
+  if (!(range_sigma > 0.0)) return fail(c, MCLHIP_E_ARG, "range_sigma must be positive");
+  MCL_TRY(upload_zmeas(c, z_meas));
+  // integers of the motion sampler uniform on [-1000, 1000): np.random.randint(-1000, 1000, 12) (mc_localization2.py:23)
+  MCL_TRY(enqueue_sample(c, v, omega, dt, alpha, 2, seed, c->spans, true, nullptr, range_sigma, 2000));
+  MCL_TRY(launch_mean_weight(c));
+  MCL_HIP(c, hipStreamSynchronize(c->stream));
+  span_collect(c, c->spans);
+  if (w_avg_out) MCL_HIP(c, hipMemcpy(w_avg_out, c->scal + 2, sizeof(double), hipMemcpyDeviceToHost));
+  return MCLHIP_OK;
+}
+
+int mclhip_resample_augmented_device(mclhip_ctx* c, double r, double p_random, double extent_x, double extent_y,
+                                     uint64_t seed, int64_t* n_injected_out) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, true, false, true));
+  if (!(extent_x > 0) || !(extent_y > 0)) return fail(c, MCLHIP_E_ARG, "empty extent");
+  if (!c->counters) MCL_TRY(dev_alloc(c, &c->counters, 16 * sizeof(uint32_t)));
+  MCL_HIP(c, hipMemsetAsync(c->counters, 0, 2 * sizeof(uint32_t), c->stream));
+  const bool any = p_random > 0.0;        // also false for NaN, as `rand() <= nan` is
+  const double al[6] = {0, 0, 0, 0, 0, 0};
+  MotionParams mp = make_motion_params(c, 0.0, 0.0, 0.0, al, 0, seed);
+  // self.X[m] = (x, y, a) in place, before the walk reads X (mc_localization2.py:284-286)
+  if (any) MCL_TRY(launch_inject_device(c, c->cur, mp, p_random, extent_x, extent_y, seed, false, c->counters));
+  MCL_TRY(launch_resample(c, r, MCLHIP_RESAMPLE_PARALLEL));
+  // the injected positions themselves: pose and weight 1/M (:287-288)
+  if (any) MCL_TRY(launch_inject_device(c, c->cur, mp, p_random, extent_x, extent_y, seed, true, c->counters));
+  uint32_t cnt[2] = {0, 0};
+  MCL_HIP(c, hipMemcpyAsync(cnt, c->counters, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
+  MCL_HIP(c, hipStreamSynchronize(c->stream));
+  if (n_injected_out) *n_injected_out = (int64_t)cnt[0];
+  if (cnt[1]) return fail(c, MCLHIP_E_STATE, "no free cell found for an injected pose (is any cell of the map 255 inside the extent?)");
   return MCLHIP_OK;
 }
 

@@ -31,6 +31,17 @@ __device__ inline void philox4x32(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
   }
 }
 
+// Two independent standard normals from two 32-bit words: Box-Muller in float32 on the hardware's log2 / sqrt /
+// sin / cos (sin and cos take their argument in turns, so the uniform number goes in as it is).  For streams
+// that are the device's own (not numpy's), where the contract is the distribution.
+__device__ inline void box_muller_f32(uint32_t a, uint32_t b, double* n0, double* n1) {
+  const float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0, 1)
+  const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);            // [0, 1), in turns
+  const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1)
+  *n0 = (double)(rad * __builtin_amdgcn_cosf(u2));
+  *n1 = (double)(rad * __builtin_amdgcn_sinf(u2));
+}
+
 // Sum of twelve scaled integers in the order numpy's pairwise reduction uses
 // for n = 12 (mc_localization.py:23-24: `r.sum()`): eight accumulators
 // combined as a tree, then the four remaining terms one by one.

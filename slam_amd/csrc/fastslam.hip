@@ -112,18 +112,10 @@ __device__ inline double wrap_residual(double d) {
   return d;
 }
 
-// four independent standard normals from one block of the counter-based generator: two Box-Muller pairs in
-// float32 on the hardware's log2 / sqrt / sin / cos (sin and cos take their argument in turns, so the uniform
-// number goes in as it is).  The draws of a device-noise run are its own stream, not numpy's: what matters is
-// their distribution, and a 24-bit uniform with single-precision transcendentals gives a normal whose error is
-// far below the sensor noise it models.
-__device__ inline void box_muller_f32(uint32_t a, uint32_t b, double* n0, double* n1) {
-  const float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0, 1)
-  const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);            // [0, 1), in turns
-  const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1)
-  *n0 = (double)(rad * __builtin_amdgcn_cosf(u2));
-  *n1 = (double)(rad * __builtin_amdgcn_sinf(u2));
-}
+// four independent standard normals from one block of the counter-based generator (two float32 Box-Muller
+// pairs).  The draws of a device-noise run are its own stream, not numpy's: what matters is their distribution,
+// and a 24-bit uniform with single-precision transcendentals gives a normal whose error is far below the sensor
+// noise it models.
 __device__ inline void device_normal_quad(uint64_t particle, uint32_t draw, uint64_t seed, double out[4]) {
   uint32_t ctr[4] = {(uint32_t)particle, (uint32_t)(particle >> 32), draw, 0x4653u};
   philox4x32(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));

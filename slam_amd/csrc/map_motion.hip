@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void motion_kernel(T* __restrict__ xs, T* __re
         uint32_t ctr[4] = {(uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)b, 0x4d434cu};
         philox4x32(ctr, (uint32_t)mp.seed, (uint32_t)(mp.seed >> 32));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) k[b * 4 + j] = (int)(((uint64_t)ctr[j] * 2001ull) >> 32) - 1000;
+        for (int j = 0; j < 4; ++j) k[b * 4 + j] = (int)(((uint64_t)ctr[j] * (uint64_t)mp.ints_span) >> 32) - 1000;
       }
     }
     v_hat = mp.v + mp.c1 * sum12(k);          // mc_localization.py:89
@@ -246,6 +246,57 @@ __global__ __launch_bounds__(256) void init_particles_kernel(T* __restrict__ xs,
   }
   if (!ok) atomicAdd(failures, 1u);
   xs[i] = (T)x; ys[i] = (T)y; ths[i] = (T)a;
+}
+
+// Random-pose injection of augmented MCL drawn on the device (mc_localization2.py:266-288): position m is
+// injected when its uniform draw is <= p_random; the pose is uniform over [0, ext_x) x [0, ext_y) on a free
+// cell (value 255), heading U[0, 2pi).  The draws are a function of (global position, seed) alone, so the
+// two passes -- poses written over X[m] in place before the walk reads X, and pose + weight 1/M written to
+// the resampled set afterwards -- see the same values without storing them.
+template <typename T>
+__global__ __launch_bounds__(256) void inject_device_kernel(T* __restrict__ xs, T* __restrict__ ys, T* __restrict__ ths,
+                                                            double* __restrict__ w, int64_t n, MotionParams mp, InitParams ip,
+                                                            double p_random, double w_value, int set_weight,
+                                                            uint32_t* __restrict__ counters) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t gi = (uint64_t)(mp.index0 + i);
+  uint32_t s[4] = {(uint32_t)gi, (uint32_t)(gi >> 32), 0u, 0x494e4a30u};
+  philox4x32(s, (uint32_t)ip.seed, (uint32_t)(ip.seed >> 32));
+  if (!(uniform01(s[0], s[1]) <= p_random)) return;          // :267
+  double x = 0.0, y = 0.0;
+  bool ok = false;
+  for (int t = 0; t < ip.max_tries && !ok; ++t) {             // :271-280
+    uint32_t c[4] = {(uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)t, 0x494e4a31u};
+    philox4x32(c, (uint32_t)ip.seed, (uint32_t)(ip.seed >> 32));
+    x = uniform01(c[0], c[1]) * ip.ext_x;
+    y = uniform01(c[2], c[3]) * ip.ext_y;
+    ok = on_free_cell(x, y, mp);
+  }
+  if (!ok) { atomicAdd(&counters[1], 1u); return; }
+  const double a = uniform01(s[2], s[3]) * M_PI * 2.0;       // :281
+  xs[i] = (T)x; ys[i] = (T)y; ths[i] = (T)a;
+  if (set_weight) w[i] = w_value;                             // :288
+  else atomicAdd(&counters[0], 1u);
+}
+
+int launch_inject_device(mclhip_ctx* c, int which_buffer, const MotionParams& mp, double p_random, double ext_x,
+                         double ext_y, uint64_t seed, bool set_weight, uint32_t* d_counters) {
+  InitParams ip;
+  ip.gaussian = 0; ip.ext_x = ext_x; ip.ext_y = ext_y; ip.x0 = ip.y0 = ip.th0 = 0.0;
+  ip.seed = seed; ip.max_tries = 4096;
+  const int b = which_buffer;
+  const int64_t n = c->M;
+  dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  const double wv = 1.0 / (double)c->M;
+  if (c->dtype == MCLHIP_F32)
+    hipLaunchKernelGGL(inject_device_kernel<float>, grid, block, 0, c->stream, (float*)c->px[b], (float*)c->py[b],
+                       (float*)c->pth[b], c->w[b], n, mp, ip, p_random, wv, set_weight ? 1 : 0, d_counters);
+  else
+    hipLaunchKernelGGL(inject_device_kernel<double>, grid, block, 0, c->stream, (double*)c->px[b], (double*)c->py[b],
+                       (double*)c->pth[b], c->w[b], n, mp, ip, p_random, wv, set_weight ? 1 : 0, d_counters);
+  MCL_HIP(c, hipGetLastError());
+  return MCLHIP_OK;
 }
 
 int launch_init_particles(mclhip_ctx* c, void* x, void* y, void* th, int64_t n, const MotionParams& mp, int gaussian,

@@ -50,6 +50,10 @@ struct RayParams {
   double p_rand;         // 1/z_max
   const double* range_noise;  // [n][B] additive noise on the predicted ranges, caller beam order (augmented MCL) or null
   int no_obstacles;      // the map holds no obstacle cell
+  // augmented MCL with device-drawn range noise: sigma * N(0, 1) per (particle, beam), keyed by the global particle index
+  double rn_sigma;
+  uint64_t rn_seed;
+  int64_t rn_index0;
   unsigned long long* stamps;  // profiling build only: cycles per kernel section
   // histogram-filter update (one pose per free grid cell)
   const int32_t* g_cell;       // flat cell index of pose p
@@ -71,6 +75,7 @@ struct MotionParams {
   const uint64_t* freeb; // free-cell bit plane, tiled like the obstacle plane
   int TW, TH, W, H;
   int noise_mode;        // 0 none, 1 pre-drawn integers, 2 device generator
+  uint32_t ints_span;    // device generator: integers uniform on [-1000, -1000 + ints_span): 2001 (random_integers) or 2000 (randint)
   int book;              // 1: Table 5.3 as printed (05_robot_motion/sample_motion_model_velocity.py:90-108): no straight-line branch, no map
   uint64_t seed;
   int64_t index0;        // global index of particle 0 (keys the device generator)
@@ -220,13 +225,15 @@ int launch_nbr_count(mclhip_ctx* c, uint32_t* d_cnt);
 int launch_nbr_fill(mclhip_ctx* c);
 int launch_motion(mclhip_ctx* c, void* x, void* y, void* th, uint8_t* pm, int64_t n, const MotionParams& mp,
                   const int16_t* d_noise, int dtype);
+int launch_inject_device(mclhip_ctx* c, int which_buffer, const mcl::MotionParams& mp, double p_random, double ext_x,
+                         double ext_y, uint64_t seed, bool set_weight, uint32_t* d_counters);
 int launch_restore(mclhip_ctx* c, void* x, void* y, void* th, double* w, const void* sx, const void* sy, const void* sth,
                    const double* sw, int64_t n, int dtype);
 int launch_init_particles(mclhip_ctx* c, void* x, void* y, void* th, int64_t n, const MotionParams& mp, int gaussian,
                           double ext_x, double ext_y, const double* x0, uint64_t seed, uint32_t* d_failures);
 int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, const uint8_t* pm, int64_t n,
                    int dtype, double* w_out, double* logw_out, double* ranges_out, int32_t* hits_out,
-                   const double* range_noise = nullptr);
+                   const double* range_noise = nullptr, double rn_sigma = 0.0, uint64_t rn_seed = 0);
 int launch_mean_weight(mclhip_ctx* c);
 int launch_sequential_total(mclhip_ctx* c);   // c->cdf_exact = strictly sequential running sum of the live weights
 void fs_release(mclhip_ctx* c);

@@ -30,6 +30,7 @@
 // Compiled with -ffp-contract=off.
 #include <cstdlib>
 
+#include "device_rng.h"
 #include "mclhip_internal.h"
 
 namespace mcl {
@@ -137,7 +138,8 @@ __device__ __attribute__((noinline)) double slow_log(double v) { return log(v); 
 // WPB: wavefronts per block.  Four for the particle filter; the histogram filter's table (all headings x
 // beams) makes the per-wave LDS array large, and more waves behind one copy of the block-wide tables is
 // what lifts its occupancy.
-template <typename T, bool STAGE, bool PRODUCT, bool GRID = false, int WPB = kWavesPerBlock>
+// RNOISE: the predicted ranges get device-drawn noise (augmented MCL at particle counts the host cannot draw for).
+template <typename T, bool STAGE, bool PRODUCT, bool GRID = false, int WPB = kWavesPerBlock, bool RNOISE = false>
 __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (sizeof(T) == 4 ? MCL_RAY_WAVES : 4))) void raycast_kernel(
     RayParams P, const T* __restrict__ xs, const T* __restrict__ ys, const T* __restrict__ ths,
     const uint8_t* __restrict__ pm, int64_t n, double* __restrict__ w_out, double* __restrict__ logw_out,
@@ -520,7 +522,16 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (sizeo
         } else {
           zd = sqrt(r2);
         }
-        if (P.range_noise) {
+        if constexpr (RNOISE) {
+          // one counter block per (particle, beam in caller order); mc_localization2.py:166-173 as below
+          const uint64_t gp = (uint64_t)(P.rn_index0 + p);
+          uint32_t ctr[4] = {(uint32_t)gp, (uint32_t)(gp >> 32), (uint32_t)s_perm[k], 0x524eu};
+          philox4x32(ctr, (uint32_t)P.rn_seed, (uint32_t)(P.rn_seed >> 32));
+          double n0, n1;
+          box_muller_f32(ctr[0], ctr[1], &n0, &n1);
+          const double term = n0 * P.rn_sigma;
+          zd = P.no_obstacles ? fmin(P.z_max, P.z_max + term) : zd + term;
+        } else if (P.range_noise) {
           // augmented MCL: r += randn()*0.15 on every predicted range (mc_localization2.py:166-168);
           // without any obstacle the reading is min(z_max, z_max + noise) (:170-173)
           const double term = P.range_noise[p * B + s_perm[k]];
@@ -641,11 +652,13 @@ int launch_grid_update(mclhip_ctx* c, const double* d_x, const double* d_y, cons
 
 int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, const uint8_t* pm, int64_t n,
                    int dtype, double* w_out, double* logw_out, double* ranges_out, int32_t* hits_out,
-                   const double* range_noise) {
+                   const double* range_noise, double rn_sigma, uint64_t rn_seed) {
   const bool product = w_out != nullptr;
   if (n <= 0) return MCLHIP_OK;
   RayParams P = make_ray_params(c);
   P.range_noise = range_noise;
+  P.rn_sigma = rn_sigma; P.rn_seed = rn_seed;
+  const bool device_noise = rn_sigma > 0.0;
   const bool stage = ranges_out != nullptr;
   const size_t lds = ray_lds_bytes(P.B, P.G, P.NB, stage || product);
   if (lds > 160 * 1024) return fail(c, MCLHIP_E_LIMIT, "beam table does not fit the kernel's LDS budget");
@@ -654,9 +667,10 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
   if (blocks > max_blocks) blocks = max_blocks;
   dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
   // large beam tables need more dynamic LDS than a kernel gets by default
-#define MCL_RAY(TT, SS, PP)                                                                                          \
+#define MCL_RAY(TT, SS, PP) MCL_RAY_N(TT, SS, PP, false)
+#define MCL_RAY_N(TT, SS, PP, NN)                                                                                    \
   do {                                                                                                               \
-    auto kern = raycast_kernel<TT, SS, PP>;                                                                          \
+    auto kern = raycast_kernel<TT, SS, PP, false, kWavesPerBlock, NN>;                                               \
     if (lds > 48 * 1024)                                                                                             \
       MCL_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                      (int)lds));                                                                     \
@@ -666,12 +680,19 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
   if (stage) {
     if (dtype != MCLHIP_F64) return fail(c, MCLHIP_E_ARG, "stage query takes float64 poses");
     MCL_RAY(double, true, false);
+  } else if (device_noise) {
+    if (dtype == MCLHIP_F32) {
+      if (product) MCL_RAY_N(float, false, true, true); else MCL_RAY_N(float, false, false, true);
+    } else {
+      if (product) MCL_RAY_N(double, false, true, true); else MCL_RAY_N(double, false, false, true);
+    }
   } else if (dtype == MCLHIP_F32) {
     if (product) MCL_RAY(float, false, true); else MCL_RAY(float, false, false);
   } else {
     if (product) MCL_RAY(double, false, true); else MCL_RAY(double, false, false);
   }
 #undef MCL_RAY
+#undef MCL_RAY_N
   MCL_HIP(c, hipGetLastError());
   return MCLHIP_OK;
 }

@@ -6,7 +6,10 @@ noisy predicted ranges inside the weight (`measure(X[m], noise=True)`, mc_locali
 the running weight means `w_avg`, `w_slow`, `w_fast` (:246-249) and random-pose injection with
 probability max(0, 1 - w_fast/w_slow) inside `resample` (:262-296).  All random draws come
 from numpy's global stream in the order the reference consumes them, so they are made on the
-host, one particle at a time, and handed to the kernels as arrays.
+host, one particle at a time, and handed to the kernels as arrays.  `noise="device"` draws them
+on the GPU instead (motion integers, one normal per particle and beam, the injection draws): the
+same distributions from the device's own generator, for particle counts at which a Python loop
+per particle and beam is not an option.
 """
 import numpy as np
 
@@ -61,6 +64,15 @@ class MCLocalization(_base.MCLocalization):
         self.sensor_ranges = self.measure(self.x_gt)
         self._push_particles()
         B = len(self.sensor_angles)
+        if self.noise == "device" and noise_ints is None and range_noise is None:
+            self._seed = int(np.random.randint(0, 2 ** 31 - 1)) * 2654435761 + 1
+            self.w_avg = np.float64(self._ctx.sample_augmented_device(ut[0], ut[1], dt, alpha, self.sensor_ranges,
+                                                                      self._seed, 0.15))
+            self.w_slow = self.w_slow + self.a_slow * (self.w_avg - self.w_slow)
+            self.w_fast = self.w_fast + self.a_fast * (self.w_avg - self.w_fast)
+            self._host_fresh = False
+            self._dev_fresh = True
+            return
         if noise_ints is None or range_noise is None:
             noise_ints = np.zeros((self.M, 3, 12), np.int16)
             range_noise = np.zeros((self.M, B))
@@ -103,6 +115,13 @@ class MCLocalization(_base.MCLocalization):
         self.w_sum = self._ctx.normalise(_lib.W_PRODUCT)
         with np.errstate(divide="ignore", invalid="ignore"):
             self.p_random = max(0.0, 1 - np.float64(self.w_fast) / np.float64(self.w_slow))
+        if self.noise == "device" and injections is None:
+            seed = int(np.random.randint(0, 2 ** 31 - 1)) * 2654435761 + 7
+            self.n_injected = self._ctx.resample_augmented_device(r, self.p_random, max_x, max_y, seed)
+            self.last_idx, self.last_injected = None, None
+            self._host_fresh = False
+            self._dev_fresh = True
+            return
         rows, poses = self.draw_injections() if injections is None else injections
         self.last_idx = self._ctx.resample_augmented(r, rows, poses)
         self.last_injected = rows

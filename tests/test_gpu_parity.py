@@ -463,3 +463,53 @@ def test_sector_query_other_geometries(res, z_max, half_deg, angles):
     assert np.array_equal(Hc.astype(np.int64), Ho)
     assert np.any(R < z_max) and np.any(R == z_max)
     ctx.close()
+
+
+def test_augmented_mcl_with_device_noise():
+    """Augmented MCL with the range noise and the injections drawn on the device: their distributions.
+    On a map without obstacles a predicted range is min(z_max, z_max + 0.15 n) (mc_localization2.py:170-173), so
+    the mean and the spread of the log-weights are those of log p over n ~ N(0, 1), which numpy gives directly;
+    the injected fraction follows p_random and injected poses stand on free cells with weight 1/M."""
+    L = _lib()
+    rng = np.random.RandomState(2)
+    M, B = 1 << 18, 4
+    grid = np.full((100, 100), 255, np.uint8)
+    grid[40:60, 40:60] = 127                       # neither free nor obstacle
+    sp = O.SensorParams()
+    ctx = L.Context(0, L.F64)
+    ctx.set_map(grid, O.RES_X, O.RES_Y)
+    _sensor(ctx, [0, 90, 180, 270])
+    X = np.stack([rng.uniform(1, 5, M), rng.uniform(1, 5, M), rng.uniform(0, 6, M)], 1)
+    ctx.set_particles(X)
+    z_meas = np.array([5.0, 4.9, 4.7, 3.0])
+    w_avg = ctx.sample_augmented_device(0.0, 0.0, 0.1, ALPHA, z_meas, 4242, 0.15)     # no motion: every pose stays free
+    _, w, logw = ctx.get_particles(True, True, True)
+    n = rng.randn(2_000_000, B)
+    zp = np.minimum(sp.z_max, sp.z_max + 0.15 * n)
+    want = np.log(O.beam_px(zp, z_meas[None, :], sp)).sum(1)
+    assert abs(logw.mean() - want.mean()) < 6 * want.std() / np.sqrt(M)
+    assert abs(logw.std() / want.std() - 1) < 0.02
+    assert np.isclose(w_avg, np.mean(w), rtol=1e-9)
+    # independent noise per particle and per beam: neighbouring particles uncorrelated
+    assert abs(np.corrcoef(logw[:-1], logw[1:])[0, 1]) < 5 / np.sqrt(M)
+    # injections
+    total = ctx.normalise(0)
+    assert total == np.sum(w)
+    n_inj = ctx.resample_augmented_device(0.3 / M, 0.25, 15.0, 15.0, 99)
+    assert abs(n_inj / M - 0.25) < 5 * np.sqrt(0.25 * 0.75 / M)
+    X2, w2, _ = ctx.get_particles()
+    fresh = w2 == 1.0 / M
+    assert abs(int(fresh.sum()) - n_inj) <= 2      # a resampled weight may equal 1/M by chance
+    u = (X2[fresh, 0] / O.RES_X + 0.5).astype(int)
+    v = (X2[fresh, 1] / O.RES_Y + 0.5).astype(int)
+    assert np.all(grid[v, u] == 255)
+    assert X2[fresh, 0].min() < 1.0 and X2[fresh, 0].max() > 14.0 and X2[fresh, 2].max() > 6.0   # the whole extent, not the cloud's box
+    # nothing is injected at p_random 0 or NaN: plain resampling
+    ctx.set_particles(X, w)
+    ctx.normalise(0)
+    idx = ctx.resample(0.3 / M)
+    ctx.set_particles(X, w)
+    ctx.normalise(0)
+    assert ctx.resample_augmented_device(0.3 / M, float("nan"), 15.0, 15.0, 99) == 0
+    assert np.array_equal(ctx.get_particles()[0], X[idx])
+    ctx.close()
