@@ -372,8 +372,14 @@ int mclhip_fs_shard_kernel(mclhip_ctx* ctx, double v, double omega, double dt, c
 /* Last running sum of this rank after mclhip_shard_finalize (the last rank's value
  * is the sum of all weights, added one by one as fast_slam1.py:411-413 does). */
 int mclhip_fs_shard_last_sum(mclhip_ctx* ctx, double* last_out);
-/* 64-bit words per particle in a feature row: 2 + 9 * capacity. */
+/* 64-bit words per particle in a feature row: 2 + 9 * slots, slots = the capacity unless
+ * mclhip_fs_set_row_slots has made the rows shorter. */
 int64_t mclhip_fs_row_words(mclhip_ctx* ctx);
+/* Largest feature count among this rank's particles; and the number of slots a feature row carries from now
+ * on (1 .. capacity, the same on every rank: at least the largest count over all ranks, so that the rows move
+ * the live features and not the unused capacity).  Packing a particle with more features than that fails. */
+int mclhip_fs_max_features(mclhip_ctx* ctx, int32_t* max_out);
+int mclhip_fs_set_row_slots(mclhip_ctx* ctx, int slots);
 /* Feature rows of the local particles [lo[k], hi[k]) -> rows (host or device memory). */
 int mclhip_fs_shard_pack(mclhip_ctx* ctx, const int64_t* lo, const int64_t* hi, int nslices, void* rows);
 /* After mclhip_shard_unpack_resample: every local particle takes the feature slots

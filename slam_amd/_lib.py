@@ -101,6 +101,8 @@ PROTOTYPES = {
                                          C.c_int, _i16_p, _dbl_p, C.c_uint64]),
     "mclhip_fs_shard_last_sum": (C.c_int, [_ctx_p, _dbl_p]),
     "mclhip_fs_row_words": (C.c_int64, [_ctx_p]),
+    "mclhip_fs_max_features": (C.c_int, [_ctx_p, C.POINTER(C.c_int32)]),
+    "mclhip_fs_set_row_slots": (C.c_int, [_ctx_p, C.c_int]),
     "mclhip_fs_shard_pack": (C.c_int, [_ctx_p, _i64_p, _i64_p, C.c_int, C.c_void_p]),
     "mclhip_fs_shard_unpack": (C.c_int, [_ctx_p, C.c_void_p, C.c_int64, C.c_int64]),
     "mclhip_timing_enable": (C.c_int, [_ctx_p, C.c_int]),
@@ -554,6 +556,14 @@ class Context:
 
     def fs_row_words(self):
         return int(self.lib.mclhip_fs_row_words(self.h))
+
+    def fs_max_features(self):
+        n = C.c_int32(0)
+        self._ck(self.lib.mclhip_fs_max_features(self.h, C.byref(n)), "mclhip_fs_max_features")
+        return n.value
+
+    def fs_set_row_slots(self, slots):
+        self._ck(self.lib.mclhip_fs_set_row_slots(self.h, int(slots)), "mclhip_fs_set_row_slots")
 
     def fs_shard_pack(self, lo, hi, rows_ptr):
         lo = np.ascontiguousarray(lo, np.int64)

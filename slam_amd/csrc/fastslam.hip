@@ -558,15 +558,19 @@ __global__ void fs_divide_kernel(double* __restrict__ w, int64_t n, const double
 // Feature rows for the exchange between ranks: per particle 2 + 9 F 64-bit words --
 // [nfeat, new_id, then per slot: m0 m1 c00 c01 c10 c11 w (doubles), i, id].  Block row y = 0 handles the
 // two counters, y = 1 + slot the slots.
-__global__ void fs_pack_rows_kernel(int64_t lo, int64_t n, int F, const int32_t* __restrict__ nfeat,
+__global__ void fs_pack_rows_kernel(int64_t lo, int64_t n, int F, int R, const int32_t* __restrict__ nfeat,
                                     const int32_t* __restrict__ newid, const double* __restrict__ feat,
-                                    unsigned long long* __restrict__ out) {
+                                    unsigned long long* __restrict__ out, int32_t* __restrict__ overflow) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const int64_t p = lo + j;
-  unsigned long long* row = out + j * (2 + (int64_t)9 * F);
+  unsigned long long* row = out + j * (2 + (int64_t)9 * R);   // R slots per row
   const int y = blockIdx.y;
-  if (y == 0) { row[0] = (unsigned long long)(long long)nfeat[p]; row[1] = (unsigned long long)(long long)newid[p]; return; }
+  if (y == 0) {
+    row[0] = (unsigned long long)(long long)nfeat[p]; row[1] = (unsigned long long)(long long)newid[p];
+    if (nfeat[p] > R) atomicMax(overflow, 2);                   // the row cannot hold this particle's features
+    return;
+  }
   const int slot = y - 1;
   if (slot >= nfeat[p]) return;
   unsigned long long* dst = row + 2 + (int64_t)9 * slot;
@@ -577,15 +581,15 @@ __global__ void fs_pack_rows_kernel(int64_t lo, int64_t n, int F, const int32_t*
   dst[8] = (unsigned long long)(long long)FLD_I(f, F_INT, 1);
 }
 
-__global__ void fs_unpack_rows_kernel(const int64_t* __restrict__ idx, int64_t row0_global, int64_t L, int64_t M, int F,
+__global__ void fs_unpack_rows_kernel(const int64_t* __restrict__ idx, int64_t row0_global, int64_t L, int64_t M, int F, int R,
                                       const unsigned long long* __restrict__ rows, int32_t* __restrict__ nfeat,
                                       int32_t* __restrict__ newid, double* __restrict__ feat) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= M) return;
   int64_t rr = idx[p] - row0_global;
   rr = rr < 0 ? 0 : (rr > L - 1 ? L - 1 : rr);
-  const unsigned long long* row = rows + rr * (2 + (int64_t)9 * F);
-  const int n = (int)(long long)row[0];
+  const unsigned long long* row = rows + rr * (2 + (int64_t)9 * R);
+  const int n = min((int)(long long)row[0], R);
   const int y = blockIdx.y;
   if (y == 0) { nfeat[p] = n; newid[p] = (int)(long long)row[1]; return; }
   const int slot = y - 1;
@@ -616,6 +620,7 @@ struct FsState {
   unsigned long long* d_sectors = nullptr;        // landmark sets per bearing sector and block of 64, then one set of all per block
   int32_t* overflow = nullptr;
   int32_t* d_maxfeat = nullptr;                   // largest feature count of a particle
+  int row_slots = 0;                              // feature slots per exchange row (<= F)
   int32_t max_feat = 0; bool max_feat_valid = false;   // its host copy; valid between the end of a step and the next step's kernels
   std::vector<double> h_truth;                    // host sides of the per-step tables (alive while their uploads are in flight)
   std::vector<unsigned long long> h_sect;
@@ -796,7 +801,7 @@ int mclhip_fs_init(mclhip_ctx* c, int64_t M, int capacity) {
   F_TRY(mclhip_set_particles(c, X.data(), nullptr, M));
   FsState* s = new FsState();
   c->fs = s;
-  s->M = M; s->F = capacity;
+  s->M = M; s->F = capacity; s->row_slots = capacity;
   s->tiles = (M + 63) / 64;
   const size_t slots = (size_t)s->tiles * capacity * 64;   // feature slots, padded to whole wavefront tiles
   for (int b = 0; b < 2; ++b) {
@@ -907,7 +912,27 @@ int mclhip_fs_shard_last_sum(mclhip_ctx* c, double* last_out) {
 
 int64_t mclhip_fs_row_words(mclhip_ctx* c) {
   if (!c || !c->fs) return 0;
-  return 2 + (int64_t)9 * ((FsState*)c->fs)->F;
+  return 2 + (int64_t)9 * ((FsState*)c->fs)->row_slots;
+}
+
+int mclhip_fs_set_row_slots(mclhip_ctx* c, int slots) {
+  if (!c) return MCLHIP_E_ARG;
+  if (!c->fs) return fail(c, MCLHIP_E_STATE, "call mclhip_fs_init first");
+  FsState* s = (FsState*)c->fs;
+  if (slots < 1 || slots > s->F) return fail(c, MCLHIP_E_ARG, "row slots outside 1..capacity");
+  s->row_slots = slots;
+  return MCLHIP_OK;
+}
+
+int mclhip_fs_max_features(mclhip_ctx* c, int32_t* out) {
+  if (!c || !out) return MCLHIP_E_ARG;
+  F_HIP(hipSetDevice(c->device));
+  if (!c->fs) return fail(c, MCLHIP_E_STATE, "call mclhip_fs_init first");
+  FsState* s = (FsState*)c->fs;
+  if (!s->max_feat_valid) F_TRY(fs_count_features(c, s, s->nfeat[s->cur]));
+  F_HIP(hipStreamSynchronize(c->stream));
+  *out = s->max_feat;
+  return MCLHIP_OK;
 }
 
 int mclhip_fs_shard_pack(mclhip_ctx* c, const int64_t* lo, const int64_t* hi, int nslices, void* rows) {
@@ -916,7 +941,7 @@ int mclhip_fs_shard_pack(mclhip_ctx* c, const int64_t* lo, const int64_t* hi, in
   if (!c->fs) return fail(c, MCLHIP_E_STATE, "call mclhip_fs_init first");
   if (!lo || !hi || nslices <= 0) return fail(c, MCLHIP_E_ARG, "lo/hi NULL or no slices");
   FsState* s = (FsState*)c->fs;
-  const int64_t words = 2 + (int64_t)9 * s->F;
+  const int64_t words = 2 + (int64_t)9 * s->row_slots;
   int64_t total = 0;
   for (int k = 0; k < nslices; ++k) {
     if (lo[k] < 0 || hi[k] > s->M || hi[k] < lo[k]) return fail(c, MCLHIP_E_ARG, "slice outside the local range");
@@ -929,13 +954,20 @@ int mclhip_fs_shard_pack(mclhip_ctx* c, const int64_t* lo, const int64_t* hi, in
   for (int k = 0; k < nslices; ++k) {
     const int64_t n = hi[k] - lo[k];
     if (n == 0) continue;
-    hipLaunchKernelGGL(fs_pack_rows_kernel, dim3((unsigned)((n + 63) / 64), s->F + 1), dim3(64), 0, c->stream, lo[k], n,
-                       s->F, s->nfeat[s->cur], s->newid[s->cur], (const double*)s->feat[s->cur], s->stage + off * words);
+    hipLaunchKernelGGL(fs_pack_rows_kernel, dim3((unsigned)((n + 63) / 64), s->row_slots + 1), dim3(64), 0, c->stream, lo[k], n,
+                       s->F, s->row_slots, s->nfeat[s->cur], s->newid[s->cur], (const double*)s->feat[s->cur],
+                       s->stage + off * words, s->overflow);
     off += n;
   }
   F_HIP(hipGetLastError());
   F_HIP(hipMemcpyAsync(rows, s->stage, (size_t)total * words * 8, hipMemcpyDefault, c->stream));
+  int32_t ov = 0;
+  F_HIP(hipMemcpyAsync(&ov, s->overflow, sizeof(ov), hipMemcpyDeviceToHost, c->stream));
   F_HIP(hipStreamSynchronize(c->stream));
+  if (ov >= 2) {
+    F_HIP(hipMemset(s->overflow, 0, sizeof(int32_t)));
+    return fail(c, MCLHIP_E_LIMIT, "a particle holds more features than an exchange row has slots (mclhip_fs_set_row_slots)");
+  }
   return MCLHIP_OK;
 }
 
@@ -945,12 +977,12 @@ int mclhip_fs_shard_unpack(mclhip_ctx* c, const void* rows, int64_t L, int64_t r
   if (!c->fs) return fail(c, MCLHIP_E_STATE, "call mclhip_fs_init first");
   if (!rows || L <= 0) return fail(c, MCLHIP_E_ARG, "rows NULL or empty");
   FsState* s = (FsState*)c->fs;
-  const int64_t words = 2 + (int64_t)9 * s->F;
+  const int64_t words = 2 + (int64_t)9 * s->row_slots;
   F_TRY(fs_stage(c, s, L * words));
   F_HIP(hipMemcpyAsync(s->stage, rows, (size_t)L * words * 8, hipMemcpyDefault, c->stream));
   const int b = 1 - s->cur;
-  hipLaunchKernelGGL(fs_unpack_rows_kernel, dim3((unsigned)((s->M + 63) / 64), s->F + 1), dim3(64), 0, c->stream, c->idx,
-                     row0_global, L, s->M, s->F, (const unsigned long long*)s->stage, s->nfeat[b], s->newid[b], s->feat[b]);
+  hipLaunchKernelGGL(fs_unpack_rows_kernel, dim3((unsigned)((s->M + 63) / 64), s->row_slots + 1), dim3(64), 0, c->stream, c->idx,
+                     row0_global, L, s->M, s->F, s->row_slots, (const unsigned long long*)s->stage, s->nfeat[b], s->newid[b], s->feat[b]);
   F_HIP(hipGetLastError());
   F_TRY(fs_count_features(c, s, s->nfeat[b]));
   F_HIP(hipStreamSynchronize(c->stream));

@@ -366,6 +366,7 @@ class ShardedFastSLAM:
     def __init__(self, ctx, dist, rank, world, m_local, capacity):
         self.ctx, self.dist, self.rank, self.world = ctx, dist, rank, world
         ctx.fs_init(int(m_local), int(capacity))
+        self.capacity = int(capacity)
         self.coll = _Coll(dist, rank, world)
         sizes = self.coll.allgather_bytes(np.int64(m_local).tobytes())
         self.sizes = [int(np.frombuffer(x, np.int64)[0]) for x in sizes]
@@ -420,6 +421,10 @@ class ShardedFastSLAM:
         gidx = np.minimum(co.allreduce_sum_i64(ctx.shard_count_below(U)), M - 1)   # the i < M-1 guard (:426)
         lo, hi, send_counts, recv_counts, glo = self._plan(gidx)
         n_send, L = int(sum(send_counts)), int(sum(recv_counts))
+        # feature rows as long as the longest feature list of any rank, not as the capacity
+        most = max(int(np.frombuffer(x, np.int64)[0]) for x in co.allgather_bytes(np.int64(ctx.fs_max_features()).tobytes()))
+        ctx.fs_set_row_slots(max(1, min(most, self.capacity)))
+        self.words = ctx.fs_row_words()
         send = co.rows(n_send)
         fsend = co.rows(n_send, self.words, co.torch.int64)
         if n_send:
