@@ -444,24 +444,25 @@ __global__ __launch_bounds__(128, FS_UPDATE_WAVES) void fs_update_kernel(const F
   int n_assoc = 0;
   int kept = 0;            // slots written so far: survivors close ranks as the pass goes
   bool slid = false;       // the previous feature was discarded, this one takes its place unvisited
-  // slot j + 1 and the measurement that picked it are on their way while slot j is worked on
-  Slot nxt = {};
-  unsigned e_nxt = kNone;
-  double zr_n = 0.0, zp_n = 0.0, bw_n = 0.0;
-  if (n_old > 0) {
-    nxt = load_slot(FREC(0));
-    e_nxt = s_inv[tid];
-    if (e_nxt != kNone) { const double* m = MREC(e_nxt); zr_n = FLD(m, M_ZR); zp_n = FLD(m, M_ZPHI); bw_n = FLD(m, M_BW); }
-  }
-  for (int j = 0; j < n_old; ++j) {
-    Slot cur = nxt;
-    const unsigned e = e_nxt;
-    const double zr = zr_n, zp = zp_n, bw = bw_n;
-    if (j + 1 < n_old) {
-      nxt = load_slot(FREC(j + 1));
-      e_nxt = s_inv[(j + 1) * 128 + tid];
-      if (e_nxt != kNone) { const double* m = MREC(e_nxt); zr_n = FLD(m, M_ZR); zp_n = FLD(m, M_ZPHI); bw_n = FLD(m, M_BW); }
+  // slot j + 1 and the measurement that picked it are on their way while slot j is worked on (two ahead: no gain)
+  struct Ahead { Slot sl; unsigned e; double zr, zp, bw; };
+  auto fetch = [&](int jj) {
+    Ahead a;
+    a.sl = Slot{1.0, 0.0, M2{1.0, 0.0, 0.0, 1.0}, 0.0, 0, 0};
+    a.e = kNone; a.zr = a.zp = a.bw = 0.0;
+    if (jj < n_old) {
+      a.sl = load_slot(FREC(jj));
+      a.e = s_inv[jj * 128 + tid];
+      if (a.e != kNone) { const double* m = MREC(a.e); a.zr = FLD(m, M_ZR); a.zp = FLD(m, M_ZPHI); a.bw = FLD(m, M_BW); }
     }
+    return a;
+  };
+  Ahead a1 = fetch(0);
+  for (int j = 0; j < n_old; ++j) {
+    Slot cur = a1.sl;
+    const unsigned e = a1.e;
+    const double zr = a1.zr, zp = a1.zp, bw = a1.bw;
+    a1 = fetch(j + 1);
     const bool upd = e != kNone;
     if (upd) {
       M2 H;
