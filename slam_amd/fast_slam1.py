@@ -43,12 +43,26 @@ class Feature:
     def __init__(self, m=None, Cov=None):
         self.m, self.Cov, self.i, self.w, self.id = m, Cov, 1, 0, 0
 
+    def copy(self):
+        """fast_slam1.py:60-77 (the per-step prediction fields are not part of the view)."""
+        f = Feature(self.m.copy(), self.Cov.copy())
+        f.i, f.w, f.id = self.i, self.w, self.id
+        return f
+
 
 class Particle:
     """Read-only view of one particle (fast_slam1.py:79-84): path, feature list, weight."""
 
     def __init__(self):
         self.x, self.feature, self.w, self.new_feature_id = [], [], 0, 0
+
+    def copy(self):
+        """fast_slam1.py:86-95."""
+        y = Particle()
+        y.x = self.x.copy()
+        y.feature = [f.copy() for f in self.feature]
+        y.w, y.new_feature_id = self.w, self.new_feature_id
+        return y
 
 
 class FastSLAM:
@@ -109,6 +123,15 @@ class FastSLAM:
     def sample_normal_distribution(self, b):
         r = np.random.randint(-1000, 1000, size=12) * 0.001
         return b / 6.0 * r.sum()
+
+    def sample_motion_model_velocity(self, xt_1, ut, dt=0.1):
+        """Table 5.3 for one pose, no straight-line branch (fast_slam1.py:167-189): the three times twelve
+        integers come from np.random.randint as `sample_normal_distribution` draws them, the pose from the GPU."""
+        ints = np.stack([np.random.randint(-1000, 1000, size=12) for _ in range(3)])[None]
+        pose = np.array([np.ravel(v)[0] for v in (xt_1[0], xt_1[1], xt_1[2])], np.float64).reshape(1, 3)
+        out = self._ctx.motion_book(pose, ut[0], ut[1], dt, alpha, ints)[0]
+        shape = np.shape(xt_1[0])
+        return [np.reshape(v, shape) if shape else v for v in out]
 
     def inv_h(self, z, xt):
         return [z[0, 0] * np.cos(z[1, 0] + xt[2, 0]) + xt[0, 0], z[0, 0] * np.sin(z[1, 0] + xt[2, 0]) + xt[1, 0]]

@@ -255,3 +255,26 @@ def test_many_landmarks_in_range_and_none():
         assert np.array_equal(idx, orc.last_idx), t
         _compare(ctx.fs_get_state(), orc.state(cap), t)
     assert max(seen) >= 255 and min(seen) == 0, seen
+
+
+def test_one_pose_motion_sampler_and_copies():
+    """FastSLAM.sample_motion_model_velocity (fast_slam1.py:167-189) for one pose under a seeded stream, against the
+    oracle's pose sampler fed the same integers; Particle.copy / Feature.copy are deep."""
+    from slam_amd import fast_slam1 as S
+    slam = S.FastSLAM(M=4)
+    np.random.seed(5)
+    ints = np.stack([np.random.randint(-1000, 1000, size=12) for _ in range(3)])
+    np.random.seed(5)
+    x0 = np.array([[1.5, -2.0, 0.7]]).T
+    out = slam.sample_motion_model_velocity(x0, [25, 0.3], dt=S.dt)
+    want = F.sample_pose(x0[:, 0], [25, 0.3], ints, dt=S.dt)
+    assert np.shape(out[0]) == (1,) and rel_err(np.ravel(out), want[:, 0]) < 1e-12
+    flat = slam.sample_motion_model_velocity([1.5, -2.0, 0.7], [25, 0.3])
+    assert np.ndim(flat[0]) == 0
+    slam.control([25, 0.001])
+    y = slam.Y[0]
+    z = y.copy()
+    assert len(z.feature) == len(y.feature) and z.x is not y.x
+    if y.feature:
+        z.feature[0].m[0, 0] += 1.0
+        assert z.feature[0].m[0, 0] != y.feature[0].m[0, 0]
