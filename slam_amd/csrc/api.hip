@@ -26,7 +26,7 @@ RayParams make_ray_params(const mclhip_ctx* c) {
   RayParams P;
   P.nbr_off = c->nbr_off;
   P.nbr_cells = c->nbr_cells;
-  P.ETW = c->ETW; P.ETH = c->ETH; P.rtx = c->rtx; P.rty = c->rty;
+  P.ETW = c->ETW << kQueryShift; P.ETH = c->ETH << kQueryShift; P.rtx = c->rtx << kQueryShift; P.rty = c->rty << kQueryShift;
   P.W = c->W;
   P.res_xf = (float)c->res_x; P.res_yf = (float)c->res_y;
   P.res_x = c->res_x; P.res_y = c->res_y;
@@ -82,7 +82,7 @@ int build_ring_table(mclhip_ctx* c) {
   // neighbourhood lists over the tile grid extended by the ring radius
   c->rtx = rtx; c->rty = rty;
   c->ETW = c->TW + 2 * rtx; c->ETH = c->TH + 2 * rty;
-  const size_t ne = (size_t)c->ETW * c->ETH;
+  const size_t ne = ((size_t)c->ETW << kQueryShift) * ((size_t)c->ETH << kQueryShift);   // query tiles
   uint32_t* d_cnt = nullptr;
   MCL_HIP(c, hipMalloc((void**)&d_cnt, ne * sizeof(uint32_t)));
   int rc = launch_nbr_count(c, d_cnt);

@@ -45,58 +45,95 @@ int launch_build_tiles(mclhip_ctx* c, const uint8_t* d_map) {
 }
 
 // ---------------------------------------------------------------------------
-// Neighbourhood lists.  For every tile of the grid (extended by the ring radius on each side) the
-// obstacle cells of all tiles the ring table names, concatenated nearest tile first: what a
-// particle standing anywhere in that tile has to look at is then one contiguous slice.
+// Neighbourhood lists.  For every query tile of the grid (kQueryCells^2 cells; the grid extended by the ring
+// radius on each side) the obstacle cells of all 8x8 obstacle tiles that can hold a cell within reach of some
+// point of the query tile, concatenated nearest tile first: what a particle standing anywhere in that query
+// tile has to look at is then one contiguous slice.  The ring table names the obstacle tiles around the
+// 8x8 tile the query tile lies in; of those, the ones whose nearest cell is out of reach of the query tile
+// itself are left out.
 // ---------------------------------------------------------------------------
-__global__ void nbr_count_kernel(const uint32_t* __restrict__ tile_off, int TW, int TH, const uint16_t* __restrict__ ring,
-                                 int n_ring, int rtx, int rty, int ETW, int ETH, uint32_t* __restrict__ cnt) {
+struct NbrGeom {
+  int TW, TH, n_ring, rtx, rty, ETW, ETH;   // obstacle tiles, ring, extended 8x8 tile grid
+  double res_x, res_y, reach2;
+};
+
+// fewest whole cells between the query rows / columns [q0, q0 + kQueryCells) and the obstacle tile's [8 o, 8 o + 8)
+__device__ inline int cell_gap(int q0, int o) {
+  const int q1 = q0 + kQueryCells - 1, o0 = o * 8, o1 = o0 + 7;
+  return o0 > q1 ? o0 - q1 - 1 : (q0 > o1 ? q0 - o1 : 0);
+}
+
+__device__ inline bool in_reach(const NbrGeom& g, int qrow0, int qcol0, int y, int x) {
+  const double gx = (double)cell_gap(qcol0, x) * g.res_x, gy = (double)cell_gap(qrow0, y) * g.res_y;
+  return gx * gx + gy * gy <= g.reach2;
+}
+
+__global__ void nbr_count_kernel(const uint32_t* __restrict__ tile_off, const uint16_t* __restrict__ ring, NbrGeom g,
+                                 uint32_t* __restrict__ cnt) {
+  const int SW = g.ETW << kQueryShift, SH = g.ETH << kQueryShift;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= ETW * ETH) return;
-  const int ty = t / ETW - rty, tx = t % ETW - rtx;
+  if (t >= SW * SH) return;
+  const int sy = t / SW, sx = t % SW;
+  const int ty = (sy >> kQueryShift) - g.rty, tx = (sx >> kQueryShift) - g.rtx;   // the 8x8 tile it lies in
+  const int qrow0 = ty * 8 + (sy & ((1 << kQueryShift) - 1)) * kQueryCells;
+  const int qcol0 = tx * 8 + (sx & ((1 << kQueryShift) - 1)) * kQueryCells;
   uint32_t n = 0;
-  for (int r = 0; r < n_ring; ++r) {
+  for (int r = 0; r < g.n_ring; ++r) {
     const int y = ty + (int)(ring[r] >> 8) - 128, x = tx + (int)(ring[r] & 0xffu) - 128;
-    if (y < 0 || y >= TH || x < 0 || x >= TW) continue;
-    const uint32_t* to = tile_off + ((size_t)y * TW + x);
+    if (y < 0 || y >= g.TH || x < 0 || x >= g.TW) continue;
+    if (!in_reach(g, qrow0, qcol0, y, x)) continue;
+    const uint32_t* to = tile_off + ((size_t)y * g.TW + x);
     n += to[1] - to[0];
   }
   cnt[t] = n;
 }
 
-// one wavefront per extended tile
+// one wavefront per query tile
 __global__ __launch_bounds__(256) void nbr_fill_kernel(const uint32_t* __restrict__ tile_off,
-                                                       const uint32_t* __restrict__ cells, int TW, int TH,
-                                                       const uint16_t* __restrict__ ring, int n_ring, int rtx, int rty,
-                                                       int ETW, int ETH, const uint32_t* __restrict__ nbr_off,
+                                                       const uint32_t* __restrict__ cells, const uint16_t* __restrict__ ring,
+                                                       NbrGeom g, const uint32_t* __restrict__ nbr_off,
                                                        uint32_t* __restrict__ nbr_cells) {
+  const int SW = g.ETW << kQueryShift, SH = g.ETH << kQueryShift;
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (t >= ETW * ETH) return;
-  const int ty = t / ETW - rty, tx = t % ETW - rtx;
+  if (t >= SW * SH) return;
+  const int sy = t / SW, sx = t % SW;
+  const int ty = (sy >> kQueryShift) - g.rty, tx = (sx >> kQueryShift) - g.rtx;
+  const int qrow0 = ty * 8 + (sy & ((1 << kQueryShift) - 1)) * kQueryCells;
+  const int qcol0 = tx * 8 + (sx & ((1 << kQueryShift) - 1)) * kQueryCells;
   uint32_t out = nbr_off[t];
-  for (int r = 0; r < n_ring; ++r) {
+  for (int r = 0; r < g.n_ring; ++r) {
     const int y = ty + (int)(ring[r] >> 8) - 128, x = tx + (int)(ring[r] & 0xffu) - 128;
-    if (y < 0 || y >= TH || x < 0 || x >= TW) continue;
-    const uint32_t* to = tile_off + ((size_t)y * TW + x);
+    if (y < 0 || y >= g.TH || x < 0 || x >= g.TW) continue;
+    if (!in_reach(g, qrow0, qcol0, y, x)) continue;
+    const uint32_t* to = tile_off + ((size_t)y * g.TW + x);
     const uint32_t o = to[0], n = to[1] - o;   // n <= 64
     if ((uint32_t)lane < n) nbr_cells[out + lane] = cells[o + lane];
     out += n;
   }
 }
 
+static NbrGeom nbr_geom(const mclhip_ctx* c) {
+  NbrGeom g;
+  g.TW = c->TW; g.TH = c->TH; g.n_ring = c->n_ring; g.rtx = c->rtx; g.rty = c->rty; g.ETW = c->ETW; g.ETH = c->ETH;
+  g.res_x = c->res_x; g.res_y = c->res_y;
+  const double reach = c->z_max + 2.0 * (c->res_x + c->res_y);   // the ring table's own margin
+  g.reach2 = reach * reach;
+  return g;
+}
+
 int launch_nbr_count(mclhip_ctx* c, uint32_t* d_cnt) {
-  const int ne = c->ETW * c->ETH;
-  hipLaunchKernelGGL(nbr_count_kernel, dim3((ne + 255) / 256), dim3(256), 0, c->stream, c->tile_off, c->TW, c->TH,
-                     c->ring, c->n_ring, c->rtx, c->rty, c->ETW, c->ETH, d_cnt);
+  const int64_t ne = ((int64_t)c->ETW << kQueryShift) * ((int64_t)c->ETH << kQueryShift);
+  hipLaunchKernelGGL(nbr_count_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, c->stream, c->tile_off, c->ring,
+                     nbr_geom(c), d_cnt);
   MCL_HIP(c, hipGetLastError());
   return MCLHIP_OK;
 }
 
 int launch_nbr_fill(mclhip_ctx* c) {
-  const int ne = c->ETW * c->ETH;
-  hipLaunchKernelGGL(nbr_fill_kernel, dim3((ne + 3) / 4), dim3(256), 0, c->stream, c->tile_off, c->cells, c->TW, c->TH,
-                     c->ring, c->n_ring, c->rtx, c->rty, c->ETW, c->ETH, c->nbr_off, c->nbr_cells);
+  const int64_t ne = ((int64_t)c->ETW << kQueryShift) * ((int64_t)c->ETH << kQueryShift);
+  hipLaunchKernelGGL(nbr_fill_kernel, dim3((unsigned)((ne + 3) / 4)), dim3(256), 0, c->stream, c->tile_off, c->cells, c->ring,
+                     nbr_geom(c), c->nbr_off, c->nbr_cells);
   MCL_HIP(c, hipGetLastError());
   return MCLHIP_OK;
 }

@@ -20,12 +20,22 @@ constexpr int kScanBlock = 256;   // threads per scan block
 constexpr int kScanItems = 8;     // elements per thread in the scans
 constexpr int kScanTile = kScanBlock * kScanItems;
 
+// Neighbourhood lists are kept per QUERY tile of (8 >> kQueryShift)^2 cells: the smaller the query tile, the
+// fewer cells of its list lie outside a particle's disk (and the more lists there are).  Measured at 2^20 x 180
+// on the 4096^2 map: 4x4 query tiles cut the fetched cells per particle from 270 to 240 (obstacle tiles stay 8x8)
+// at four times the list memory, and leave the kernel time where it was -- hence 8x8.
+#ifndef MCL_QUERY_SHIFT
+#define MCL_QUERY_SHIFT 0
+#endif
+constexpr int kQueryShift = MCL_QUERY_SHIFT;        // 0: 8x8 cells, 1: 4x4, 2: 2x2
+constexpr int kQueryCells = 8 >> kQueryShift;
+
 // Everything the sector-query kernel needs about the map and the sensor.
 struct RayParams {
-  const uint32_t* nbr_off;   // [ETH*ETW + 1] start of each tile's neighbourhood list in nbr_cells[]
+  const uint32_t* nbr_off;   // [ETH*ETW + 1] start of each query tile's neighbourhood list in nbr_cells[]
   const uint32_t* nbr_cells; // per tile: the obstacle cells (row << 16 | col) of every tile that can hold a cell
                              // within z_max of a point of that tile, nearest tile first
-  int ETW, ETH, rtx, rty;    // the tile grid is extended by rtx / rty tiles on each side (poses just outside the map)
+  int ETW, ETH, rtx, rty;    // the query-tile grid, extended by rtx / rty query tiles on each side (poses just outside the map)
   int W;                     // map width in cells (hit cells are reported as row * W + col)
   float res_xf, res_yf;  // float32 cell size: cell-centre coordinates are float32 products
   double res_x, res_y;

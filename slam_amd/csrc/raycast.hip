@@ -232,8 +232,8 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (sizeo
     // ring table's two cells of slack)
     const double fxc = x * inv_res_x, fyc = y * inv_res_y;
     const bool pose_ok = (fabs(fxc) < 1.0e6) && (fabs(fyc) < 1.0e6);
-    const int tcx = pose_ok ? ((int)floor(fxc)) >> 3 : 0;
-    const int tcy = pose_ok ? ((int)floor(fyc)) >> 3 : 0;
+    const int tcx = pose_ok ? ((int)floor(fxc)) >> (3 - kQueryShift) : 0;   // query tile
+    const int tcy = pose_ok ? ((int)floor(fyc)) >> (3 - kQueryShift) : 0;
     // the particle's slice of neighbourhood cells; NaN / infinite headings match no beam
     unsigned int first_cell = 0u, n_cells = 0u;
     {
