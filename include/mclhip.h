@@ -392,7 +392,8 @@ int mclhip_fs_shard_unpack(mclhip_ctx* ctx, const void* rows, int64_t L, int64_t
  * which: 0 = sector-query + likelihood kernel, 1 = motion kernel,
  *        2 = normalise + resample + gather kernels together,
  *        3 = grid prediction, 4 = grid update.
- * Enabling resets the accumulators. */
+ * on: 0 off, 1 every group, 2 the sector-query kernel only (two events per step instead of six: an event between
+ * two kernels costs a few microseconds of idle GPU).  Enabling resets the accumulators. */
 int mclhip_timing_enable(mclhip_ctx* ctx, int on);
 int mclhip_timing_get(mclhip_ctx* ctx, int which, int64_t* launches, double* total_ms);
 

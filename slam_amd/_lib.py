@@ -595,7 +595,8 @@ class Context:
         return out
 
     def timing_enable(self, on=True):
-        self._ck(self.lib.mclhip_timing_enable(self.h, 1 if on else 0), "mclhip_timing_enable")
+        """on: False / True (every kernel group) / 2 (the sector-query kernel only)."""
+        self._ck(self.lib.mclhip_timing_enable(self.h, 2 if on == 2 else (1 if on else 0)), "mclhip_timing_enable")
 
     def timing_get(self, which):
         n = C.c_int64(0)

@@ -158,14 +158,17 @@ static int use(mclhip_ctx* c) {
 // timing: events are recorded around kernel groups and read back after the
 // stream has been synchronised
 static void span_begin(mclhip_ctx* c, std::vector<mclhip_ctx::Span>& v, int which) {
-  if (!c->timing) return;
+  c->span_open = false;
+  if (!c->timing || (c->timing == 2 && which != 0)) return;
+  c->span_open = true;
   mclhip_ctx::Span s; s.which = which;
   (void)hipEventCreate(&s.a); (void)hipEventCreate(&s.b);
   (void)hipEventRecord(s.a, c->stream);
   v.push_back(s);
 }
 static void span_end(mclhip_ctx* c, std::vector<mclhip_ctx::Span>& v) {
-  if (!c->timing || v.empty()) return;
+  if (!c->span_open || v.empty()) return;
+  c->span_open = false;
   (void)hipEventRecord(v.back().b, c->stream);
 }
 static void span_collect(mclhip_ctx* c, std::vector<mclhip_ctx::Span>& v) {
@@ -1095,7 +1098,7 @@ int mclhip_shard_unpack_resample(mclhip_ctx* c, const void* rows, int64_t L, dou
 
 int mclhip_timing_enable(mclhip_ctx* c, int on) {
   if (!c) return MCLHIP_E_ARG;
-  c->timing = on != 0;
+  c->timing = on == 2 ? 2 : (on != 0 ? 1 : 0);
   for (int i = 0; i < 5; ++i) { c->t_launch[i] = 0; c->t_ms[i] = 0; }
   return MCLHIP_OK;
 }

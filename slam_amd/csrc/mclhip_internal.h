@@ -204,7 +204,8 @@ struct mclhip_ctx {
   void* fs = nullptr;               // FastSLAM storage (fastslam.hip owns the type)
 
   // timing
-  bool timing = false;
+  int timing = 0;            // 0 off, 1 every kernel group, 2 the sector-query kernel only
+  bool span_open = false;    // the last span_begin recorded an event
   int64_t t_launch[5] = {0, 0, 0, 0, 0};
   double t_ms[5] = {0, 0, 0, 0, 0};
   struct Span { hipEvent_t a, b; int which; };

@@ -47,17 +47,30 @@ __device__ double pairwise(const double* a, int n) {
 // combine the eight accumulators as ((0+1)+(2+3))+((4+5)+(6+7)), bits 3..5
 // combine the eight leaves a wave holds, and the eight wave results are
 // combined in the same left/right order -- numpy's recursion tree for n = 8192.
-__global__ __launch_bounds__(512) void chunk_sum_kernel(const double* __restrict__ w, int64_t n,
-                                                        double* __restrict__ chunk_sums) {
+// FROM_LOG: the weights are formed on the way in, w = exp(logw - max logw) (0 when every log-weight is -inf),
+// and written out for the kernels that follow.
+template <bool FROM_LOG>
+__global__ __launch_bounds__(512) void chunk_sum_kernel(double* __restrict__ w, int64_t n, double* __restrict__ chunk_sums,
+                                                        const double* __restrict__ logw, const double* __restrict__ scal) {
   __shared__ double wave_sum[8];
   const int64_t base = (int64_t)blockIdx.x * kSumChunk;
   const int cnt = (int)((n - base) < kSumChunk ? (n - base) : kSumChunk);
+  const double mx = FROM_LOG ? scal[1] : 0.0;
+  auto weight = [&](int64_t i) -> double {
+    if constexpr (FROM_LOG) {
+      const double v = (mx == -INFINITY) ? 0.0 : exp(logw[i] - mx);
+      w[i] = v;
+      return v;
+    } else {
+      return w[i];
+    }
+  };
   if (cnt == kSumChunk) {
     const int leaf = threadIdx.x >> 3, j = threadIdx.x & 7;
-    const double* a = w + base + leaf * 128 + j;
-    double r = a[0];
+    const int64_t a = base + leaf * 128 + j;
+    double r = weight(a);
 #pragma unroll
-    for (int g = 1; g < 16; ++g) r = r + a[8 * g];
+    for (int g = 1; g < 16; ++g) r = r + weight(a + 8 * g);
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) r = r + __shfl_xor(r, d, 64);
     if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = r;
@@ -66,6 +79,10 @@ __global__ __launch_bounds__(512) void chunk_sum_kernel(const double* __restrict
       chunk_sums[blockIdx.x] = ((wave_sum[0] + wave_sum[1]) + (wave_sum[2] + wave_sum[3])) +
                                ((wave_sum[4] + wave_sum[5]) + (wave_sum[6] + wave_sum[7]));
   } else {
+    if constexpr (FROM_LOG) {
+      for (int i = threadIdx.x; i < cnt; i += blockDim.x) (void)weight(base + i);
+      __syncthreads();                       // the block's own stores are visible to its thread 0
+    }
     if (threadIdx.x == 0) chunk_sums[blockIdx.x] = pairwise<7>(w + base, cnt);
   }
 }
@@ -80,6 +97,23 @@ __global__ void total_sum_kernel(const double* __restrict__ chunk_sums, int nchu
 __global__ void divide_kernel(double* __restrict__ w, int64_t n, const double* __restrict__ scal) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) w[i] = w[i] / scal[0];  // mc_localization.py:248
+}
+
+// the same with the total formed on the spot: every block adds the chunk sums left to right (numpy's order across
+// chunks; a few hundred additions at most), block 0 leaves the total in scal[0] for the caller
+__global__ __launch_bounds__(256) void total_divide_kernel(double* __restrict__ w, int64_t n,
+                                                           const double* __restrict__ chunk_sums, int nchunks,
+                                                           double* __restrict__ scal) {
+  __shared__ double s_total;
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < nchunks; ++i) t = t + chunk_sums[i];
+    s_total = t;
+    if (blockIdx.x == 0) scal[0] = t;
+  }
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) w[i] = w[i] / s_total;  // mc_localization.py:248
 }
 
 // log-domain weights: w = exp(logw - max logw)
@@ -106,29 +140,29 @@ __global__ __launch_bounds__(256) void max_final_kernel(const double* __restrict
   if (threadIdx.x == 0) scal[1] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
 }
 
-__global__ void exp_shift_kernel(const double* __restrict__ logw, double* __restrict__ w, int64_t n,
-                                 const double* __restrict__ scal) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const double mx = scal[1];
-  w[i] = (mx == -INFINITY) ? 0.0 : exp(logw[i] - mx);
-}
 
 int launch_normalise(mclhip_ctx* c, int mode) {
   const int64_t n = c->M;
   double* w = c->w[c->cur];
   const unsigned g = (unsigned)((n + 255) / 256);
+  const int nchunks = (int)((n + kSumChunk - 1) / kSumChunk);
   if (mode == MCLHIP_W_LOG) {
     const int np = 1024;
     hipLaunchKernelGGL(max_partial_kernel, dim3(np), dim3(256), 0, c->stream, c->logw, n, (double*)c->blk_a);
     hipLaunchKernelGGL(max_final_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)c->blk_a, np, c->scal);
-    hipLaunchKernelGGL(exp_shift_kernel, dim3(g), dim3(256), 0, c->stream, c->logw, w, n, c->scal);
+    hipLaunchKernelGGL(chunk_sum_kernel<true>, dim3(nchunks), dim3(512), 0, c->stream, w, n, c->chunk_sums,
+                       (const double*)c->logw, (const double*)c->scal);
+  } else {
+    hipLaunchKernelGGL(chunk_sum_kernel<false>, dim3(nchunks), dim3(512), 0, c->stream, w, n, c->chunk_sums,
+                       (const double*)nullptr, (const double*)nullptr);
   }
-  const int nchunks = (int)((n + kSumChunk - 1) / kSumChunk);
-  hipLaunchKernelGGL(chunk_sum_kernel, dim3(nchunks), dim3(512), 0, c->stream, w, n,
-                     c->chunk_sums);
-  hipLaunchKernelGGL(total_sum_kernel, dim3(1), dim3(64), 0, c->stream, c->chunk_sums, nchunks, c->scal);
-  hipLaunchKernelGGL(divide_kernel, dim3(g), dim3(256), 0, c->stream, w, n, c->scal);
+  if (nchunks <= 1024) {
+    hipLaunchKernelGGL(total_divide_kernel, dim3(g), dim3(256), 0, c->stream, w, n, (const double*)c->chunk_sums, nchunks,
+                       c->scal);
+  } else {   // very many chunks: one pass over them, not one per block
+    hipLaunchKernelGGL(total_sum_kernel, dim3(1), dim3(64), 0, c->stream, c->chunk_sums, nchunks, c->scal);
+    hipLaunchKernelGGL(divide_kernel, dim3(g), dim3(256), 0, c->stream, w, n, c->scal);
+  }
   MCL_HIP(c, hipGetLastError());
   return MCLHIP_OK;
 }
@@ -485,7 +519,8 @@ int launch_shard_weights(mclhip_ctx* c, int mode, double gmax) {
   if (mode == MCLHIP_W_LOG)
     hipLaunchKernelGGL(exp_shift_by_kernel, dim3(g), dim3(256), 0, c->stream, c->logw, w, n, gmax);
   const int nchunks = (int)((n + kSumChunk - 1) / kSumChunk);
-  hipLaunchKernelGGL(chunk_sum_kernel, dim3(nchunks), dim3(512), 0, c->stream, w, n, c->chunk_sums);
+  hipLaunchKernelGGL(chunk_sum_kernel<false>, dim3(nchunks), dim3(512), 0, c->stream, w, n, c->chunk_sums,
+                     (const double*)nullptr, (const double*)nullptr);
   MCL_HIP(c, hipGetLastError());
   return MCLHIP_OK;
 }
@@ -494,10 +529,9 @@ int launch_shard_weights(mclhip_ctx* c, int mode, double gmax) {
 int launch_dshard_weights(mclhip_ctx* c) {
   const int64_t n = c->M;
   double* w = c->w[c->cur];
-  const unsigned g = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(exp_shift_kernel, dim3(g), dim3(256), 0, c->stream, c->logw, w, n, (const double*)c->scal);
   const int nchunks = (int)((n + kSumChunk - 1) / kSumChunk);
-  hipLaunchKernelGGL(chunk_sum_kernel, dim3(nchunks), dim3(512), 0, c->stream, w, n, c->chunk_sums);
+  hipLaunchKernelGGL(chunk_sum_kernel<true>, dim3(nchunks), dim3(512), 0, c->stream, w, n, c->chunk_sums,
+                     (const double*)c->logw, (const double*)c->scal);
   MCL_HIP(c, hipGetLastError());
   return MCLHIP_OK;
 }
