@@ -104,10 +104,13 @@ __global__ void divide_kernel(double* __restrict__ w, int64_t n, const double* _
 __global__ __launch_bounds__(256) void total_divide_kernel(double* __restrict__ w, int64_t n,
                                                            const double* __restrict__ chunk_sums, int nchunks,
                                                            double* __restrict__ scal) {
+  __shared__ double s_chunk[1024];
   __shared__ double s_total;
+  for (int i = threadIdx.x; i < nchunks; i += blockDim.x) s_chunk[i] = chunk_sums[i];   // one parallel read ...
+  __syncthreads();
   if (threadIdx.x == 0) {
     double t = 0.0;
-    for (int i = 0; i < nchunks; ++i) t = t + chunk_sums[i];
+    for (int i = 0; i < nchunks; ++i) t = t + s_chunk[i];                                // ... one serial chain of additions
     s_total = t;
     if (blockIdx.x == 0) scal[0] = t;
   }
