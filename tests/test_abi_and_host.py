@@ -98,3 +98,17 @@ def test_workload_generators_are_deterministic():
     u = np.trunc(X[:, 0] / W.RES + 0.5).astype(int)
     v = np.trunc(X[:, 1] / W.RES + 0.5).astype(int)
     assert np.all(a[v, u] == 255)
+
+
+def test_particle_filter_histogram_matches_reference():
+    """ParticleFilter.update_pdf (host part of the chapter-4 drop-in) on the resampled sets the reference produced:
+    weights accumulated per rounded position in particle order, then normalised -- bit for bit."""
+    from slam_amd import particle_filter as pf
+    g = load("particle_filter04")
+    for n in range(int(g["n_cases"])):
+        flt = pf.ParticleFilter.__new__(pf.ParticleFilter)      # no device needed for this method
+        flt.M, flt.x_max = len(g["c%d_w" % n]), int(g["x_max"])
+        flt.px = np.zeros(flt.x_max)
+        flt.X, flt.w = list(g["c%d_X_out" % n]), list(g["c%d_w_out" % n])
+        flt.update_pdf()
+        assert np.array_equal(flt.px, g["c%d_px" % n]), n
