@@ -112,6 +112,18 @@ int64_t mclhip_num_particles(mclhip_ctx* ctx);
  * of the nearest obstacle cell inside each beam's sector, -1 = none. */
 int mclhip_raycast(mclhip_ctx* ctx, const double* poses_aos, int64_t n, double* ranges, int32_t* hit_cell);
 
+/* mclhip_raycast for callers that cannot allocate device memory (a serving loop
+ * that measures one true pose per step, code under HIP graph capture around it,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same
+ * arguments and results as mclhip_raycast, but the staging the kernels need (poses,
+ * ranges and hit cells on the device) lives in a 960-KiB array inside the library's
+ * code object instead of being allocated and freed per call, so the call performs
+ * no hipMalloc / hipFree.  Limits: n <= 4096 and n * B <= 65536, more is refused with
+ * MCLHIP_E_LIMIT.  Map and sensor must both be set (the map tables are built by
+ * mclhip_set_map / mclhip_set_sensor, whichever comes second).  Every context on one
+ * GPU shares that GPU's array: calls that overlap on one GPU race. */
+int mclhip_raycast_static(mclhip_ctx* ctx, const double* poses_aos, int64_t n, double* ranges, int32_t* hit_cell);
+
 /* Replaces MCLocalization.sample_motion_model_velocity (mc_localization.py:74-114)
  * over n poses.  noise_ints: [n][3][12] integers in [-1000, 1000], the values
  * np.random.random_integers(-1000, 1000, 12) would return for the three draws

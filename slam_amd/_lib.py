@@ -40,6 +40,7 @@ PROTOTYPES = {
     "mclhip_get_particles": (C.c_int, [_ctx_p, _dbl_p, _dbl_p, _dbl_p]),
     "mclhip_num_particles": (C.c_int64, [_ctx_p]),
     "mclhip_raycast": (C.c_int, [_ctx_p, _dbl_p, C.c_int64, _dbl_p, _i32_p]),
+    "mclhip_raycast_static": (C.c_int, [_ctx_p, _dbl_p, C.c_int64, _dbl_p, _i32_p]),
     "mclhip_motion": (C.c_int, [_ctx_p, _dbl_p, C.c_int64, C.c_double, C.c_double, C.c_double, _dbl_p, _i16_p,
                                 _dbl_p, _dbl_p]),
     "mclhip_motion_book": (C.c_int, [_ctx_p, _dbl_p, C.c_int64, C.c_double, C.c_double, C.c_double, _dbl_p, _i16_p,
@@ -208,12 +209,17 @@ class Context:
         return X, w, lw
 
     # stages -----------------------------------------------------------------
-    def raycast(self, poses, want_hits=True):
+    def raycast(self, poses, want_hits=True, static=False):
+        """static: through mclhip_raycast_static (no device allocation; at most 4096 poses / 65536 pose-beam pairs)."""
         P = _f64(poses).reshape(-1, 3)
         n = len(P)
         R = np.empty((n, self.B))
         Hc = np.empty((n, self.B), np.int32) if want_hits else None
-        self._ck(self.lib.mclhip_raycast(self.h, _p(P, _dbl_p), n, _p(R, _dbl_p), _p(Hc, _i32_p)), "mclhip_raycast")
+        if static:
+            self._ck(self.lib.mclhip_raycast_static(self.h, _p(P, _dbl_p), n, _p(R, _dbl_p), _p(Hc, _i32_p)),
+                     "mclhip_raycast_static")
+        else:
+            self._ck(self.lib.mclhip_raycast(self.h, _p(P, _dbl_p), n, _p(R, _dbl_p), _p(Hc, _i32_p)), "mclhip_raycast")
         return R, Hc
 
     def motion(self, poses, v, omega, dt, alpha, noise_ints=None):

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <numeric>
 #include <vector>
 
@@ -21,6 +22,49 @@ int fail(mclhip_ctx* c, int code, const std::string& msg) {
 size_t irr_record_bytes();
 size_t run_base_bytes();
 size_t kf_bytes();
+
+// ---- device memory of mclhip_raycast_static ----------------------------------------------------------
+// The stage query needs staging on the device beside the caller's host buffers: the poses as passed,
+// their structure-of-arrays form, and the ranges / hit cells before they are copied back.  mclhip_raycast
+// allocates and frees that per call; mclhip_raycast_static keeps it in the code object instead.  Every GPU
+// the library runs on holds its own copy of the array (960 KiB) at its own address until the process ends.
+constexpr int64_t kStaticMaxPoses = 4096;      // poses per call
+constexpr int64_t kStaticMaxEntries = 65536;   // poses x beams per call
+constexpr size_t kStaticOffAos = 0;                                                          // [n][3] float64
+constexpr size_t kStaticOffX = kStaticOffAos + (size_t)kStaticMaxPoses * 3 * sizeof(double);   // [n] float64 each
+constexpr size_t kStaticOffY = kStaticOffX + (size_t)kStaticMaxPoses * sizeof(double);
+constexpr size_t kStaticOffTh = kStaticOffY + (size_t)kStaticMaxPoses * sizeof(double);
+constexpr size_t kStaticOffRanges = kStaticOffTh + (size_t)kStaticMaxPoses * sizeof(double);   // [n][B] float64
+constexpr size_t kStaticOffHits = kStaticOffRanges + (size_t)kStaticMaxEntries * sizeof(double);   // [n][B] int32
+constexpr size_t kStaticBytes = kStaticOffHits + (size_t)kStaticMaxEntries * sizeof(int32_t);
+static __device__ __align__(256) unsigned char scratch[kStaticBytes];
+
+// In host code `scratch` is only a handle of the symbol, not an address a kernel or a copy can use: the
+// address of each device's copy is looked up once per device (with that device current) and kept here.
+constexpr int kMaxDevices = 64;
+static std::mutex g_scratch_mutex;
+static unsigned char* g_scratch_ptr[kMaxDevices] = {};
+static hipError_t g_scratch_err[kMaxDevices] = {};
+
+// called from mclhip_create with the context's device current
+static void resolve_static_scratch(int device) {
+  if (device < 0 || device >= kMaxDevices) return;
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (g_scratch_ptr[device]) return;
+  void* p = nullptr;
+  const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+  g_scratch_err[device] = e;
+  if (e == hipSuccess) g_scratch_ptr[device] = static_cast<unsigned char*>(p);
+}
+
+__global__ void split_poses_kernel(const double* __restrict__ aos, int64_t n, double* __restrict__ x,
+                                   double* __restrict__ y, double* __restrict__ th) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  x[i] = aos[3 * i];
+  y[i] = aos[3 * i + 1];
+  th[i] = aos[3 * i + 2];
+}
 
 RayParams make_ray_params(const mclhip_ctx* c) {
   RayParams P;
@@ -279,6 +323,7 @@ int mclhip_create(mclhip_ctx** out, int device, int dtype) {
   if (e == hipSuccess) e = hipMalloc((void**)&c->scal, 8 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&c->stamps, 16 * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMemset(c->stamps, 0, 16 * sizeof(unsigned long long));
+  if (e == hipSuccess) resolve_static_scratch(device);
   if (e != hipSuccess) {
     fail(nullptr, MCLHIP_E_HIP, std::string("context set-up failed: ") + hipGetErrorString(e));
     delete c;
@@ -352,6 +397,9 @@ int mclhip_set_map(mclhip_ctx* c, const uint8_t* map, int H, int W, double res_x
   if (e != hipSuccess) return fail(c, MCLHIP_E_HIP, std::string("map upload: ") + hipGetErrorString(e));
   if (rc != MCLHIP_OK) return rc;
   if (e2 != hipSuccess) return fail(c, MCLHIP_E_HIP, std::string("map tiling: ") + hipGetErrorString(e2));
+  // with map and sensor both known the neighbourhood lists are built here, so that the calls that use them
+  // allocate nothing (mclhip_raycast_static relies on it)
+  if (c->B > 0) MCL_TRY(build_ring_table(c));
   return MCLHIP_OK;
 }
 
@@ -364,7 +412,9 @@ int mclhip_set_sensor(mclhip_ctx* c, const double* angles_deg, int B, double z_m
     if (!std::isfinite(angles_deg[k])) return fail(c, MCLHIP_E_ARG, "beam angles must be finite");
   std::vector<double> tab(B);
   for (int k = 0; k < B; ++k) tab[k] = angles_deg[k] * M_PI / 180.0;  // angle*np.pi/180.0 (mc_localization.py:143)
-  return mcl::set_sensor_table(c, tab.data(), B, z_max, sigma_hit, lambda_short, w4, half);
+  MCL_TRY(mcl::set_sensor_table(c, tab.data(), B, z_max, sigma_hit, lambda_short, w4, half));
+  if (c->obst) MCL_TRY(build_ring_table(c));   // see mclhip_set_map
+  return MCLHIP_OK;
 }
 
 }  // extern "C"
@@ -544,6 +594,40 @@ int mclhip_raycast(mclhip_ctx* c, const double* poses, int64_t n, double* ranges
   (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dt); (void)hipFree(dr); (void)hipFree(dh);
   if (rc != MCLHIP_OK) return rc;
   if (e != hipSuccess) return fail(c, MCLHIP_E_HIP, std::string("raycast: ") + hipGetErrorString(e));
+  return MCLHIP_OK;
+}
+
+int mclhip_raycast_static(mclhip_ctx* c, const double* poses, int64_t n, double* ranges, int32_t* hit_cell) {
+  MCL_TRY(use(c));
+  if (!c->obst) return fail(c, MCLHIP_E_STATE, "no map: call mclhip_set_map first");
+  if (c->B == 0) return fail(c, MCLHIP_E_STATE, "no sensor: call mclhip_set_sensor first");
+  if (c->ring_dirty)   // building them allocates; mclhip_set_map / mclhip_set_sensor do it once both are known
+    return fail(c, MCLHIP_E_STATE, "map tables are not built: set the map and the sensor with mclhip_set_map / mclhip_set_sensor");
+  if (!poses || !ranges || n <= 0) return fail(c, MCLHIP_E_ARG, "poses/ranges NULL or n <= 0");
+  const int B = c->B;
+  if (n > kStaticMaxPoses || n * (int64_t)B > kStaticMaxEntries)
+    return fail(c, MCLHIP_E_LIMIT, "mclhip_raycast_static takes at most 4096 poses and 65536 (pose, beam) pairs per call; "
+                                   "use mclhip_raycast for more");
+  unsigned char* const base = (c->device >= 0 && c->device < kMaxDevices) ? g_scratch_ptr[c->device] : nullptr;
+  if (!base)
+    return fail(c, MCLHIP_E_HIP, std::string("address of the static device array is not known: ") +
+                                     hipGetErrorString(c->device >= 0 && c->device < kMaxDevices ? g_scratch_err[c->device]
+                                                                                                : hipErrorInvalidDevice));
+  double* const d_aos = reinterpret_cast<double*>(base + kStaticOffAos);
+  double* const dx = reinterpret_cast<double*>(base + kStaticOffX);
+  double* const dy = reinterpret_cast<double*>(base + kStaticOffY);
+  double* const dt = reinterpret_cast<double*>(base + kStaticOffTh);
+  double* const dr = reinterpret_cast<double*>(base + kStaticOffRanges);
+  int32_t* const dh = reinterpret_cast<int32_t*>(base + kStaticOffHits);
+  MCL_HIP(c, hipMemcpyAsync(d_aos, poses, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(split_poses_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                     (const double*)d_aos, n, dx, dy, dt);
+  MCL_HIP(c, hipGetLastError());
+  // the kernel writes every (pose, beam) entry of ranges and hit cells: nothing of the last call's contents is read
+  MCL_TRY(launch_raycast(c, dx, dy, dt, nullptr, n, MCLHIP_F64, nullptr, nullptr, dr, dh));
+  MCL_HIP(c, hipMemcpyAsync(ranges, dr, (size_t)n * B * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (hit_cell) MCL_HIP(c, hipMemcpyAsync(hit_cell, dh, (size_t)n * B * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  MCL_HIP(c, hipStreamSynchronize(c->stream));
   return MCLHIP_OK;
 }
 

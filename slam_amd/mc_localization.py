@@ -213,7 +213,8 @@ class MCLocalization:
         """Ranges of all beams from pose xt (mc_localization.py:116-171): distance to the nearest
         obstacle-cell centre inside each beam's +-5 degree sector, z_max if none."""
         self._push_config()
-        R, _ = self._ctx.raycast(np.asarray(xt, np.float64).reshape(1, 3), want_hits=False)
+        # one pose per filter step: the variant that allocates no device memory per call
+        R, _ = self._ctx.raycast(np.asarray(xt, np.float64).reshape(1, 3), want_hits=False, static=True)
         out = [np.float64(r) for r in R[0]]
         if noise:
             out = [r + np.random.randn() * 0.15 for r in out]
