@@ -2,6 +2,7 @@
 """Benchmark of the MCL update (BASELINE.json: particle-beam evaluations per second).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N ...                      (starts N ranks itself, one per GPU)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 One step = one whole update of the particle set: restore the synthetic cloud
@@ -28,6 +29,8 @@ if ROOT not in sys.path:
 
 ALGO_BYTES_PER_EVAL = 97.2   # 96.96 one-byte grid cells per +-5 deg sector of radius z_max/res + 0.22 B particle state
 HBM_PEAK_GBS = 8000.0
+SIMDS = 1024                 # 256 compute units x 4 SIMD-32
+PEAK_CLOCK_GHZ = 2.4
 
 
 def parse():
@@ -46,7 +49,62 @@ def parse():
                     help="multi-rank step with the host combining the ranks' small results (default: device-driven)")
     ap.add_argument("--rehearse-collectives", action="store_true",
                     help="run the multi-rank code path (RCCL group, cross-rank resampling) even with one rank")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend of a multi-rank run (gloo: host-combined exchange, for rehearsals)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="every rank uses GPU 0 (rehearsal of the multi-rank path on a one-GPU box; needs --backend gloo)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher check without a GPU: the ranks rendezvous over gloo and rank 0 prints the line")
     return ap.parse_args()
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher around it: start N fresh rank processes (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment) and wait for them.  The parent touches no GPU.  Rank 0 writes the
+    JSON line to this process's stdout; the exit status is non-zero if any rank fails."""
+    import socket
+    import subprocess
+    n = a.gpus
+    if not (a.dry_run or a.share_gpu):
+        import torch
+        have = torch.cuda.device_count()          # counts devices without initialising the GPU runtime
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible\n" % (n, have))
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        pending = list(range(n))
+        while pending:
+            for r in list(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.remove(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    sys.stderr.write("bench.py: rank %d exited with status %d\n" % (r, code))
+            if rc:
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:              # a failed rank leaves the others waiting in a collective
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    return rc
 
 
 def cpu_baseline(grid, angles, X, z_meas, ut, n_particles):
@@ -93,33 +151,90 @@ def stream_copy_ceiling(torch):
     return 2.0 * n * 4 / (ms * 1e-3) / 1e9
 
 
-def profiled_traffic(args):
-    """HBM bytes per launch of the sector-query kernel from the committed rocprofv3 counter passes
-    (profiles/rNN_pmc_per_kernel.json; FETCH_SIZE and WRITE_SIZE are in KiB, collected in separate
-    passes; FETCH_SIZE doubled as gfx950 tallies 128-B requests at 64 B).  Only valid for the
-    default workload the passes were run on; None otherwise."""
+def profiled_mix(args):
+    """What the committed counter passes say about one launch of the sector-query kernel on the default workload
+    (profiles/rNN_valu_roofline.json, written by tools/valu_roofline.py from rocprofv3 --pmc passes): vector
+    wave-instructions priced with their measured issue cost, the hardware's own count of VALU-active cycles, and the
+    HBM bytes (FETCH_SIZE doubled, as gfx950 tallies 128-byte requests at 64 bytes, + WRITE_SIZE; separate passes).
+    Only valid for the workload the passes were run on; None otherwise."""
     import glob
     if (args.particles, args.beams, args.map, args.dtype, args.regime) != (1 << 20, 180, 4096, "f32", "global"):
         return None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_per_kernel.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_roofline.json")))
     if not files:
         return None
     d = json.load(open(files[-1]))
-    for name, ctr in d.items():
-        if "raycast_kernel<float, false, false" in name and "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
-            return (2.0 * ctr["FETCH_SIZE"]["per_launch_mean"] + ctr["WRITE_SIZE"]["per_launch_mean"]) * 1024.0
-    return None
+    d["file"] = os.path.relpath(files[-1], ROOT)
+    return d
+
+
+def roofline(args, M, B, ray_ms, n_ray, copy_gbs):
+    """The sector-query kernel against the ceiling that binds it.  It is bound by vector-instruction issue: per
+    particle it issues several hundred vector instructions and reads about 1.5 KB, so the figure a launch is held to
+    is (vector wave-instructions x issue cycles each) / (SIMDs x clock), with the kernel time measured live; the
+    measured HBM rate stands beside it."""
+    mix = profiled_mix(args)
+    peak = SIMDS * PEAK_CLOCK_GHZ                       # G SIMD issue cycles per second
+    out = {"bound": "valu", "achieved": None, "peak": peak, "unit": "G SIMD issue-cycles/s", "frac": None, "traffic": None,
+           "kernel": "raycast_kernel (sector query + beam likelihood)", "kernel_ms": ray_ms, "launches": n_ray,
+           "peak_is": "%d SIMD-32 x %.1f GHz" % (SIMDS, PEAK_CLOCK_GHZ),
+           "algorithmic_bytes_per_eval": ALGO_BYTES_PER_EVAL,
+           "algorithmic_bytes_per_launch": ALGO_BYTES_PER_EVAL * float(M) * B,
+           "stream_copy_GBps": copy_gbs}
+    if mix and n_ray:
+        sec = ray_ms * 1e-3
+        cyc = mix["priced_issue_cycles_per_launch"]
+        out["achieved"] = cyc / sec / 1e9
+        out["frac"] = out["achieved"] / peak
+        out["issue_cycles_per_launch"] = cyc
+        out["valu_wave_instructions_per_launch"] = mix["valu_wave_instructions_per_launch"]
+        out["valu_active_cycles_per_launch_hw"] = mix["hardware_valu_active_cycles_per_launch"]
+        out["frac_hw_valu_active"] = mix["hardware_valu_active_cycles_per_launch"] / sec / 1e9 / peak
+        out["traffic"] = mix["hbm_bytes_per_launch"]
+        out["traffic_unit"] = "HBM bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, %s)" % mix["file"]
+        if mix["hbm_bytes_per_launch"]:
+            gbs = mix["hbm_bytes_per_launch"] / sec / 1e9
+            out["hbm"] = {"achieved_GBps": gbs, "peak_GBps": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
+                          "l2_hit_rate": mix.get("l2_hit_rate")}
+        out["source"] = mix["file"]
+    return out
+
+
+def dry_run(a, rank, world, json_fd):
+    """Launcher check: rendezvous over gloo, one collective, rank 0 prints a line that says how many ranks it saw."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        line = json.dumps({"metric": "particle-beam evals/sec (node) + ms per MCL step, 1M particles x 180 beams",
+                           "value": None, "unit": "particle-beam evals/s", "n_gpus": world, "dry_run": True,
+                           "world_size_seen": int(t.item()), "steps": a.steps, "warmup": a.warmup})
+        os.write(json_fd, (line + "\n").encode())
+    dist.destroy_process_group()
 
 
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a))          # this process starts the ranks and touches no GPU itself
     # stdout carries exactly one JSON line: whatever libraries print on the way (RCCL's version banner
     # goes to stdout) is sent to stderr instead
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    if a.dry_run:
+        return dry_run(a, int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), json_fd)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d; running %d rank(s)\n" % (a.gpus, world, world))
+    if a.share_gpu:
+        if world > 1 and a.backend != "gloo":
+            sys.exit("bench.py: --share-gpu needs --backend gloo (RCCL refuses two ranks on one device)")
+        local_rank = 0
     import torch
     dist = None
     if world > 1 or a.rehearse_collectives:
@@ -129,6 +244,8 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        elif a.backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from slam_amd import _lib, workload as W
@@ -186,7 +303,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
-        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
     n_ray, ms_ray = ctx.timing_get(0)
@@ -204,12 +321,12 @@ def main():
         evals_step = float(M) * world * B
         ms_step = elapsed / a.steps * 1e3
         ray_ms = ms_ray / max(n_ray, 1)
-        achieved = ALGO_BYTES_PER_EVAL * float(M) * B / (ray_ms * 1e-3) / 1e9 if n_ray else None
         out = {
             "metric": "particle-beam evals/sec (node) + ms per MCL step, 1M particles x 180 beams",
             "value": evals_step / (elapsed / a.steps),
             "unit": "particle-beam evals/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "n_gpus": world, "world_size_seen": (dist.get_world_size() if dist is not None else 1),
+            "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_step,
             "higher_is_better": True,
             "scaling": "weak",
@@ -223,15 +340,7 @@ def main():
                        "sharding": ("contiguous particle ranges, map replicated; %s" %
                                     ("device-driven exchange" if filt.device_path else "host-combined exchange"))
                        if filt.collective else "single GPU"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": profiled_traffic(a),
-                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, profiles/)",
-                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_EVAL * float(M) * B,
-                         "kernel": "raycast_kernel (sector query + beam likelihood)",
-                         "kernel_ms": ray_ms, "launches": n_ray,
-                         "algorithmic_bytes_per_eval": ALGO_BYTES_PER_EVAL,
-                         "stream_copy_GBps": copy_gbs,
-                         "frac_of_stream_copy": (achieved / copy_gbs) if achieved else None},
+            "roofline": roofline(a, M, B, ray_ms, n_ray, copy_gbs),
             "kernel_ms": {"raycast": ray_ms, "motion": ms_mot / max(n_mot, 1),
                           "normalise+resample+gather": ms_res / max(n_res, 1)},
         }

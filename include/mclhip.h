@@ -17,7 +17,9 @@
  *     process per GPU; ranks are combined by the host, see the shard_* calls);
  *   - a context is not thread-safe: one caller thread per context;
  *   - calls are synchronous (they return after the device work has finished)
- *     except mclhip_step_async().
+ *     except mclhip_step_async(), mclhip_restore_particles_async() and the
+ *     mclhip_dshard_*() calls, which only enqueue on the context's stream; every
+ *     synchronous call first waits for what those have enqueued.
  */
 #ifndef MCLHIP_H
 #define MCLHIP_H

@@ -360,6 +360,7 @@ int mclhip_set_map(mclhip_ctx* c, const uint8_t* map, int H, int W, double res_x
   if (!map || H <= 0 || W <= 0) return fail(c, MCLHIP_E_ARG, "map is NULL or empty");
   if (H > 65535 || W > 65535) return fail(c, MCLHIP_E_LIMIT, "map sides are limited to 65535 cells");
   if (!(res_x > 0) || !(res_y > 0)) return fail(c, MCLHIP_E_ARG, "cell size must be positive");
+  MCL_HIP(c, hipStreamSynchronize(c->stream));   // the map tables are replaced: nothing enqueued earlier may still read them
   c->H = H; c->W = W; c->TH = (H + 7) / 8; c->TW = (W + 7) / 8;
   c->res_x = res_x; c->res_y = res_y;
   c->ring_dirty = true;
@@ -424,6 +425,9 @@ int mcl::set_sensor_table(mclhip_ctx* c, const double* tab_rad, int B, double z_
                           double lambda_short, const double w4[4], double half) {
   if (B > kMaxBeams) return fail(c, MCLHIP_E_LIMIT, "at most 1024 beams");
   if (!(z_max > 0) || !(sigma_hit > 0) || !(half >= 0)) return fail(c, MCLHIP_E_ARG, "bad sensor constants");
+  // the tables are replaced with blocking copies: work enqueued by the calls that do not wait (mclhip_step_async,
+  // mclhip_dshard_*) must have finished with the old ones
+  MCL_HIP(c, hipStreamSynchronize(c->stream));
   c->B = B; c->z_max = z_max; c->sigma = sigma_hit; c->lambda = lambda_short; c->half = half;
   c->ring_dirty = true;
   for (int i = 0; i < 4; ++i) c->w4[i] = w4[i];
@@ -495,6 +499,7 @@ int mclhip_set_particles(mclhip_ctx* c, const double* X, const double* w, int64_
   MCL_TRY(use(c));
   if (!X || M <= 0) return fail(c, MCLHIP_E_ARG, "X is NULL or M <= 0");
   if (M > ((int64_t)1 << 31)) return fail(c, MCLHIP_E_LIMIT, "at most 2^31 particles per context");
+  MCL_HIP(c, hipStreamSynchronize(c->stream));   // blocking copies below: nothing enqueued earlier may still use the arrays
   MCL_TRY(ensure_capacity(c, M));
   c->M = M;
   c->cur = 0;
@@ -523,6 +528,7 @@ int mclhip_init_particles(mclhip_ctx* c, int64_t M, const double* x0, double ext
   MCL_TRY(need(c, true, false, false));
   if (M <= 0 || !(extent_x > 0) || !(extent_y > 0)) return fail(c, MCLHIP_E_ARG, "M <= 0 or empty extent");
   if (M > ((int64_t)1 << 31)) return fail(c, MCLHIP_E_LIMIT, "at most 2^31 particles per context");
+  MCL_HIP(c, hipStreamSynchronize(c->stream));   // the particle arrays may be reallocated
   MCL_TRY(ensure_capacity(c, M));
   c->M = M;
   c->cur = 0;
@@ -967,6 +973,7 @@ int mclhip_shard_get_records(mclhip_ctx* c, void* records_out, int64_t cap_recor
   MCL_TRY(use(c));
   MCL_TRY(need(c, false, false, true));
   uint32_t nrec = 0;
+  MCL_HIP(c, hipStreamSynchronize(c->stream));
   MCL_HIP(c, hipMemcpy(&nrec, c->fscan + (c->M - 1), sizeof(uint32_t), hipMemcpyDeviceToHost));
   if (cap_records < (int64_t)nrec || (!records_out && nrec)) return fail(c, MCLHIP_E_ARG, "records_out too small");
   if (nrec) MCL_HIP(c, hipMemcpy(records_out, c->irr, (size_t)nrec * irr_record_bytes(), hipMemcpyDeviceToHost));

@@ -296,7 +296,10 @@ class ShardedFilter:
     def step(self, v, omega, dt, alpha, z_meas, r, seed=0, noise_ints=None, want_idx=False):
         """r = (uniform draw) / M_total, identical on every rank."""
         if not self.collective:
-            self.b.step_single(v, omega, dt, alpha, z_meas, r, noise_ints, seed, self.mode, wait=want_idx)
+            # pre-drawn integers are read from the caller's buffer, so that call waits as well
+            wait = bool(want_idx) or noise_ints is not None
+            self.b.step_single(v, omega, dt, alpha, z_meas, r, noise_ints, seed, self.mode, wait=wait)
+            self.last_idx = self.b.ctx.get_indices() if want_idx and isinstance(self.b, HipShardBackend) else None
             return
         if self.device_path:
             ok = self._drive(self._device_step(v, omega, dt, alpha, z_meas, r, seed, noise_ints))
@@ -305,6 +308,9 @@ class ShardedFilter:
                 self.last_idx = self.b.ctx.get_indices() if want_idx else None
                 return
             self.fallbacks = getattr(self, "fallbacks", 0) + 1
+            if self.coll is None:
+                raise RuntimeError("more irregular records than the fixed exchange holds, and this filter has no "
+                                   "process group to finish the step on the host path (built by for_layout)")
             self._finish_on_host(r, want_idx)    # too many irregular records for the fixed exchange
             return
         self.b.sample(v, omega, dt, alpha, z_meas, noise_ints, seed, self.mode)

@@ -104,14 +104,27 @@ def run_ranks(fn, world, *args, backend="gloo"):
     for p in procs:
         p.start()
     out = {}
-    for _ in range(world):
-        r, val = q.get(timeout=300)
-        out[r] = val
-    for p in procs:
-        p.join(60)
-    for r in range(world):
+    try:
+        for _ in range(world):
+            r, val = q.get(timeout=300)
+            out[r] = val
+            if isinstance(val, str) and val.startswith("ERROR"):
+                break              # the other ranks may be waiting for this one in a collective: do not wait for them
+        for p in procs:
+            p.join(60 if len(out) == world else 1)
+    finally:
+        for p in procs:            # no rank outlives the test (a leftover one would keep holding the GPU)
+            if p.is_alive():
+                p.terminate()
+                p.join(10)
+                if p.is_alive():
+                    p.kill()
+                    p.join(10)
+    for r in sorted(out):
         if isinstance(out[r], str) and out[r].startswith("ERROR"):
             raise AssertionError("rank %d failed:\n%s" % (r, out[r]))
+    if len(out) != world:
+        raise AssertionError("only %d of %d ranks reported" % (len(out), world))
     return [out[r] for r in range(world)]
 
 

@@ -1,0 +1,66 @@
+"""bench.py started as `python bench.py --gpus N` brings up N ranks itself (one process per GPU) and rank 0 prints
+exactly one JSON line that says how many ranks it saw."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, BENCH] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    return p.returncode, p.stdout.decode(), p.stderr.decode()
+
+
+def test_launcher_starts_two_ranks_without_a_gpu():
+    rc, out, err = _run(["--gpus", "2", "--dry-run"])
+    assert rc == 0, err
+    lines = [x for x in out.splitlines() if x.strip()]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world_size_seen"] == 2 and d["dry_run"] is True
+
+
+def test_launcher_refuses_more_ranks_than_gpus():
+    import torch
+    n = torch.cuda.device_count() + 2
+    rc, out, err = _run(["--gpus", str(n)])
+    assert rc != 0 and out.strip() == "" and "GPU(s) visible" in err
+
+
+def test_a_failing_rank_fails_the_launcher():
+    # --share-gpu without gloo is refused inside the ranks: the parent must report failure, not hang
+    rc, out, err = _run(["--gpus", "2", "--share-gpu", "--backend", "nccl"], timeout=120)
+    assert rc != 0 and out.strip() == ""
+
+
+SMALL = ["--steps", "2", "--warmup", "1", "--particles", "65536", "--beams", "36", "--map", "512", "--cpu-particles", "0"]
+
+
+@pytest.mark.gpu
+def test_one_rank_line():
+    rc, out, err = _run(["--gpus", "1"] + SMALL)
+    assert rc == 0, err[-2000:]
+    lines = [x for x in out.splitlines() if x.strip()]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["bound"] == "valu"
+    assert d["config"]["particles_per_gpu"] == 65536
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_through_the_launcher():
+    """The real multi-process path (two rank processes, cross-rank resampling) on the test box's one GPU: gloo
+    carries the exchanges, as RCCL refuses two ranks on one device."""
+    rc, out, err = _run(["--gpus", "2", "--backend", "gloo", "--share-gpu"] + SMALL)
+    assert rc == 0, err[-2000:]
+    lines = [x for x in out.splitlines() if x.strip()]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world_size_seen"] == 2 and d["value"] > 0
+    assert "host-combined" in d["config"]["sharding"]
