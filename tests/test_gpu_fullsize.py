@@ -92,3 +92,74 @@ def test_full_step_resampling_properties(big):
     assert np.array_equal(idx, O.resample_indices(wn, r, clamp=True))
     Xr, wr, _ = ctx.get_particles()
     assert np.array_equal(wr, wn[idx])
+
+
+def _near_cell_edge(X, res, ulps=2.0):
+    """Poses whose float32 rounding can move them across a cell boundary of the free-cell test
+    (mc_localization.py:106-109 rounds x/res + 0.5 toward zero)."""
+    out = np.zeros(len(X), bool)
+    for c in (0, 1):
+        t = X[:, c] / res + 0.5
+        d = np.abs(t - np.rint(t)) * res
+        out |= d <= ulps * np.spacing(np.abs(X[:, c]).astype(np.float32)).astype(np.float64)
+    return out
+
+
+def _check_timed_instantiation(ctx, big, z_meas, seed, rng, n_pick=4096):
+    """One motion + sector query + likelihood pass exactly as bench.py times it -- float32 state, noise drawn on the
+    device, log-weights only (no raw product) -- then, for a random subset: ranges and hit cells of the device's own
+    poses bit-equal to the oracle's, log-weights within 1e-5 relative of the oracle's float64 ones."""
+    from slam_amd import _lib
+    M = big["M"]
+    ctx.shard_sample(1.5, 0.5, 0.1, ALPHA, z_meas, None, seed, _lib.W_LOG)     # the kernels of mclhip_step_async, no resampling
+    Xd, _, lwd = ctx.get_particles(True, False, True)
+    assert np.array_equal(Xd, Xd.astype(np.float32).astype(np.float64))       # float32 state
+    pick = rng.choice(M, n_pick, replace=False)
+    P = Xd[pick]
+    R, Hc = ctx.raycast(P)
+    lut, cell = big["lut"]
+    Ro, Ho = O.sector_query_batch(P, lut, cell, big["angles"])
+    assert np.array_equal(R, Ro), int(np.sum(R != Ro))
+    assert np.array_equal(Hc.astype(np.int64), Ho)
+    pm = O.free_cell(P[:, 0], P[:, 1], big["grid"])
+    _, lwo, _ = O.weights_from_ranges(Ro, z_meas, pm, big["sp"])
+    fin_d, fin_o = np.isfinite(lwd[pick]), np.isfinite(lwo)
+    # the free-cell flag is taken from the float64 pose before it is rounded to float32 for storage: the two can
+    # differ only for a pose that the rounding moved across a cell boundary
+    differ = fin_d != fin_o
+    assert np.all(_near_cell_edge(P, 0.15)[differ]) and differ.sum() <= 8, int(differ.sum())
+    both = fin_d & fin_o
+    assert both.sum() > n_pick // 2
+    err = np.abs(lwd[pick][both] - lwo[both]) / np.maximum(1.0, np.abs(lwo[both]))
+    assert err.max() < 1e-5, err.max()
+    return float(err.max()), Xd
+
+
+def test_timed_float32_instantiation_against_the_oracle(big):
+    """The configuration bench.py reports (2^20 x 180 on the 4096^2 map, float32 state, device noise, log-weights):
+    a 4096-particle subset against the oracle, in the global-localisation regime (uniform cloud) and again in the
+    tracking regime (the cloud after three resampling steps)."""
+    from slam_amd import _lib
+    ctx = big["make"](_lib.F32)
+    X, M = big["X"], big["M"]
+    big.setdefault("lut", O.obstacle_lut(big["grid"]))
+    rng = np.random.RandomState(21)
+    z_meas = ctx.raycast(X[0], want_hits=False)[0][0]
+    ctx.set_particles(X)
+    e0, _ = _check_timed_instantiation(ctx, big, z_meas, 501, rng)
+    # three whole updates (device noise, log-weights, order-exact resampling), then the same check on the clustered cloud
+    from slam_amd.mc_localization import advance_true_pose
+    ctx.set_particles(X)
+    x_gt = X[0].copy()
+    for t in range(3):
+        x_gt = advance_true_pose(x_gt, (1.5, 0.5), 0.1)
+        z = ctx.raycast(x_gt, want_hits=False)[0][0]
+        ctx.step(1.5, 0.5, 0.1, ALPHA, z, (0.11 + 0.2 * t) / M, None, 900 + t, _lib.W_LOG, wait=True)
+    x_gt = advance_true_pose(x_gt, (1.5, 0.5), 0.1)
+    z = ctx.raycast(x_gt, want_hits=False)[0][0]
+    e1, Xd = _check_timed_instantiation(ctx, big, z, 777, rng)
+    # the tracking regime: the cloud has collapsed onto a few places (the uniform cloud covers ~250000 tiles of 8x8 cells)
+    tiles = np.unique((Xd[:, 1] // 1.2).astype(np.int64) * 4096 + (Xd[:, 0] // 1.2).astype(np.int64))
+    assert len(tiles) < 5000, len(tiles)
+    print("float32 log-weight error vs oracle: global %.2e, tracking %.2e (bar 1e-5)" % (e0, e1))
+    ctx.close()
