@@ -278,6 +278,9 @@ static int upload_zmeas(mclhip_ctx* c, const double* z_meas) {
   if (c->zev_set[k]) MCL_HIP(c, hipEventSynchronize(c->zev[k]));   // the slot's previous upload
   double* host = c->zpin + (size_t)k * c->B;
   std::memcpy(host, z_meas, c->B * sizeof(double));
+  bool ok = true;
+  for (int b = 0; b < c->B; ++b) ok = ok && (z_meas[b] >= 0.0) && (z_meas[b] <= 1.0e9);   // false for NaN as well
+  c->zmeas_ok = ok;
   MCL_HIP(c, hipMemcpyAsync(c->zmeas_stage, host, c->B * sizeof(double), hipMemcpyHostToDevice, c->stream));
   MCL_HIP(c, hipEventRecord(c->zev[k], c->stream));
   c->zev_set[k] = true;

@@ -134,6 +134,7 @@ struct mclhip_ctx {
   hipEvent_t zev[kZSlots] = {};   // upload of the slot has finished
   bool zev_set[kZSlots] = {};
   int zslot = 0;
+  bool zmeas_ok = false;          // the last uploaded measurement is finite and >= 0 everywhere (what the float32 mixture assumes)
   uint16_t* ring = nullptr;       // tile visiting order of the sector query
   int n_ring = 0;
   bool ring_dirty = true;         // map resolution or z_max changed since the table was built

@@ -135,11 +135,20 @@ __device__ __attribute__((noinline)) double slow_log(double v) { return log(v); 
 #ifndef MCL_RAY_WAVES
 #define MCL_RAY_WAVES 6
 #endif
+#ifndef MCL_FAST_LIKELIHOOD
+#define MCL_FAST_LIKELIHOOD 1
+#endif
 // WPB: wavefronts per block.  Four for the particle filter; the histogram filter's table (all headings x
 // beams) makes the per-wave LDS array large, and more waves behind one copy of the block-wide tables is
 // what lifts its occupancy.
 // RNOISE: the predicted ranges get device-drawn noise (augmented MCL at particle counts the host cannot draw for).
-template <typename T, bool STAGE, bool PRODUCT, bool GRID = false, int WPB = kWavesPerBlock, bool RNOISE = false>
+// FAST: float32 state, log-weights only, measured ranges finite and >= 0 (the throughput configuration): the beam
+// mixture runs in float32 on the full-rate instructions, with the one quantity that needs more -- the difference
+// between predicted and measured range, which the Gaussian term amplifies by d / sigma^2 -- formed from the exact
+// float64 squared distance as (r2 - z*^2) / (z + z*), so that it carries float32 RELATIVE accuracy however close
+// the two ranges are.
+template <typename T, bool STAGE, bool PRODUCT, bool GRID = false, int WPB = kWavesPerBlock, bool RNOISE = false,
+          bool FAST = false>
 __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (sizeof(T) == 4 ? MCL_RAY_WAVES : 4))) void raycast_kernel(
     RayParams P, const T* __restrict__ xs, const T* __restrict__ ys, const T* __restrict__ ths,
     const uint8_t* __restrict__ pm, int64_t n, double* __restrict__ w_out, double* __restrict__ logw_out,
@@ -173,8 +182,14 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (sizeo
   }
   if (!STAGE)
     for (int k = threadIdx.x; k < NT; k += blockDim.x) {
-      s_zt[k] = P.zt[k];
-      s_el[k] = P.etalam[k];
+      if constexpr (FAST) {
+        const double zs = P.zt[k];
+        s_zt[k] = zs * zs;                                            // z*^2, float64
+        reinterpret_cast<float2*>(s_el)[k] = make_float2((float)zs, (float)(P.etalam[k] * P.w_short));
+      } else {
+        s_zt[k] = P.zt[k];
+        s_el[k] = P.etalam[k];
+      }
     }
   if (GRID) {
     for (int k = threadIdx.x; k < NE; k += blockDim.x) { s_cls[k] = P.g_cls[k]; s_member[k] = P.g_member[k]; }
@@ -490,6 +505,53 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (sizeo
         for (int k = 0; k < P.g_B0; ++k) q = q * __longlong_as_double((long long)emin[d * P.g_B0 + k]);
         P.g_pk[cell * P.g_D + d] = (float)(P.g_pk_pred[cell * P.g_D + d] * q);   // robot.py:300, float32 store
       }
+    } else if constexpr (FAST) {
+      // range_sensor.py:31-112 per beam, float32 (see the comment at the template head).  What is exact:
+      //   0 <= z <= z_max holds for every entry (r2 <= z_max^2 by construction), so p_hit and p_rand always apply;
+      //   z <= z*  <=>  r2 <= z*^2 (float64);  |z - z_max| < 1e-6  <=>  r2 > (z_max - 1e-6)^2 (float64 bit patterns).
+      const float k_hit = (float)neg_half_inv_s2_log2e, k_short = (float)neg_lambda_log2e;
+      const double chw = P.c_hit * P.w_hit;
+      const float prw = (float)(P.p_rand * P.w_rand), wmax = (float)P.w_max;
+      const double zm1 = P.z_max - 1e-6;
+      const unsigned long long near_max_bits = (unsigned long long)__double_as_longlong(zm1 > 0.0 ? zm1 * zm1 : 0.0);
+      double l2s = 0.0;          // sum of log2 of the lane's partial products
+      double prod = 1.0;
+      int nfac = 0;
+      // log2 of a partial product: exponent and mantissa split in integer arithmetic, v_log_f32 of the mantissa
+      // (in [1, 2): absolute error ~1e-7), joined in float64
+      auto log2_of_product = [&](double v) -> double {
+        const long long bits = __double_as_longlong(v);
+        const int ex = (int)((bits >> 52) & 0x7ff);
+        if (ex == 0 || ex == 0x7ff || bits < 0) return slow_log(v) * 1.4426950408889634;   // zero, subnormal, infinite, NaN
+        const double mant = __longlong_as_double((bits & 0x000fffffffffffffll) | 0x3ff0000000000000ll);
+        return (double)(ex - 1023) + (double)__builtin_amdgcn_logf((float)mant);
+      };
+      for (int k = lane; k < B; k += 64) {
+        const unsigned long long rb = rmin[G + k];
+        const double r2 = __longlong_as_double((long long)rb);
+        const float num = (float)(r2 - s_zt[k]);                      // z^2 - z*^2, cancellation exact in float64
+        const float2 zf = reinterpret_cast<const float2*>(s_el)[k];   // z*, eta * lambda * w_short
+        const float z0 = __builtin_amdgcn_sqrtf((float)r2);
+        const float den = (z0 + 1e-30f) + zf.x;                       // > 0 (both ranges 0: d = 0 * 1e30 = 0)
+        const float d = num * __builtin_amdgcn_rcpf(den);             // z - z*
+        const float e_hit = __builtin_amdgcn_exp2f((d * d) * k_hit);
+        const float e_short = __builtin_amdgcn_exp2f(z0 * k_short);
+        // the small terms in float32; the dominant one and the sum in float64: beams in the same state (typically
+        // many at z = z* = z_max) round alike, and a float32 sum would add that rounding up coherently
+        float small = prw;                                            // p_rand * w_rand
+        small = small + (num <= 0.0f ? e_short * zf.y : 0.0f);        // p_short * w_short where z <= z*
+        small = small + (rb > near_max_bits ? wmax : 0.0f);           // p_max * w_max
+        const double pk = (double)e_hit * chw + (double)small;        // + p_hit * w_hit
+        prod *= pk;
+        if (++nfac == 16) {                                           // sixteen factors >= 1e-3 cannot underflow
+          l2s += log2_of_product(prod);
+          prod = 1.0;
+          nfac = 0;
+        }
+      }
+      if (nfac) l2s += log2_of_product(prod);
+      const double lsd = wave_sum(l2s) * 0.6931471805599453;
+      if (lane == 0) logw_out[p] = on_free ? lsd : -INFINITY;
     } else {
       typedef T R;  // likelihood arithmetic follows the state dtype
       // log-weight: each lane multiplies its few p_k in float64 and takes one logarithm of the
@@ -668,9 +730,10 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
   dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
   // large beam tables need more dynamic LDS than a kernel gets by default
 #define MCL_RAY(TT, SS, PP) MCL_RAY_N(TT, SS, PP, false)
-#define MCL_RAY_N(TT, SS, PP, NN)                                                                                    \
+#define MCL_RAY_N(TT, SS, PP, NN) MCL_RAY_F(TT, SS, PP, NN, false)
+#define MCL_RAY_F(TT, SS, PP, NN, FF)                                                                                \
   do {                                                                                                               \
-    auto kern = raycast_kernel<TT, SS, PP, false, kWavesPerBlock, NN>;                                               \
+    auto kern = raycast_kernel<TT, SS, PP, false, kWavesPerBlock, NN, FF>;                                           \
     if (lds > 48 * 1024)                                                                                             \
       MCL_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                      (int)lds));                                                                     \
@@ -687,12 +750,17 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
       if (product) MCL_RAY_N(double, false, true, true); else MCL_RAY_N(double, false, false, true);
     }
   } else if (dtype == MCLHIP_F32) {
-    if (product) MCL_RAY(float, false, true); else MCL_RAY(float, false, false);
+    // log-weights only, no range noise, measured ranges finite and >= 0: the float32 mixture
+    const bool fast = !product && !range_noise && c->zmeas_ok && MCL_FAST_LIKELIHOOD;
+    if (product) MCL_RAY(float, false, true);
+    else if (fast) MCL_RAY_F(float, false, false, false, true);
+    else MCL_RAY(float, false, false);
   } else {
     if (product) MCL_RAY(double, false, true); else MCL_RAY(double, false, false);
   }
 #undef MCL_RAY
 #undef MCL_RAY_N
+#undef MCL_RAY_F
   MCL_HIP(c, hipGetLastError());
   return MCLHIP_OK;
 }

@@ -235,6 +235,24 @@ def test_f32_state_mode(name):
     fin = np.isfinite(lwo)
     assert np.array_equal(np.isfinite(logw), fin)
     assert np.max(np.abs(logw[fin] - lwo[fin]) / np.maximum(1.0, np.abs(lwo[fin]))) < 1e-5
+    # the log-weight-only pass (what the fused step and bench.py run: the float32 beam mixture)
+    ctx.set_particles(s["X_in"])
+    ctx.shard_sample(s["ut"][0], s["ut"][1], float(s["dt"]), ALPHA, s["z_meas"], s["noise"], 0, L.W_LOG)
+    X2, _, logw2 = ctx.get_particles(True, False, True)
+    assert np.array_equal(X2, X)
+    assert np.array_equal(np.isfinite(logw2), fin)
+    err = np.abs(logw2[fin] - lwo[fin]) / np.maximum(1.0, np.abs(lwo[fin]))
+    assert err.max() < 1e-5, err.max()
+    print("%s: float32 log-weight error, product pass %.2e, log-only pass %.2e" %
+          (name, np.max(np.abs(logw[fin] - lwo[fin]) / np.maximum(1.0, np.abs(lwo[fin]))), err.max()))
+    # a measurement the float32 mixture does not take (negative range): the general path answers, same bar
+    zneg = np.array(s["z_meas"], np.float64).copy()
+    zneg[0] = -0.25
+    ctx.set_particles(s["X_in"])
+    ctx.shard_sample(s["ut"][0], s["ut"][1], float(s["dt"]), ALPHA, zneg, s["noise"], 0, L.W_LOG)
+    _, _, logw3 = ctx.get_particles(False, False, True)
+    _, lwn, _ = O.weights_from_ranges(Ro, zneg, O.free_cell(X[:, 0], X[:, 1], grid), O.SensorParams())
+    assert np.max(np.abs(logw3[fin] - lwn[fin]) / np.maximum(1.0, np.abs(lwn[fin]))) < 1e-5
 
 
 def test_dropin_class_follows_reference_run():
