@@ -854,8 +854,7 @@ static int step_common(mclhip_ctx* c, double v, double omega, double dt, const d
   std::vector<mclhip_ctx::Span>& spans = c->spans;
   MCL_TRY(enqueue_sample(c, v, omega, dt, alpha, noise_ints ? 1 : 2, seed, spans, weight_mode == MCLHIP_W_PRODUCT));
   span_begin(c, spans, 2);
-  MCL_TRY(launch_normalise(c, weight_mode));
-  MCL_TRY(launch_resample(c, r, MCLHIP_RESAMPLE_PARALLEL));
+  MCL_TRY(launch_normalise_resample(c, weight_mode, r));
   span_end(c, spans);
   if (wait) {
     MCL_HIP(c, hipStreamSynchronize(c->stream));

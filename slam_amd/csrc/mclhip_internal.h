@@ -254,6 +254,7 @@ int launch_inject(mclhip_ctx* c, const int64_t* d_rows, const double* d_poses, i
 int launch_compute_px(mclhip_ctx* c, const double* z, const double* zt, int64_t n, double* p);
 int launch_normalise(mclhip_ctx* c, int mode);
 int launch_resample(mclhip_ctx* c, double r, int algo);
+int launch_normalise_resample(mclhip_ctx* c, int mode, double r);   // the two above in six launches (fused update)
 int launch_shard_max_logw(mclhip_ctx* c);
 int launch_shard_weights(mclhip_ctx* c, int mode, double gmax);
 int launch_dshard_weights(mclhip_ctx* c);

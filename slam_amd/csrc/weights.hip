@@ -377,6 +377,9 @@ __global__ void finalize_cdf_kernel(const unsigned long long* __restrict__ ks, c
 }
 
 // index(m) = number of c_i that are < U_m, U_m = r + m/M  (mc_localization.py:254-257)
+// (a two-level search -- a 1024-entry sample of the running sums staged in LDS per block, then the last ten probes in
+// memory -- was measured at 2^20 particles: 26 us against 18.5 us for this plain one; the staging round costs more
+// than the ten L2 probes it saves)
 template <typename T>
 __global__ __launch_bounds__(256) void search_gather_kernel(const double* __restrict__ cdf, int64_t n, double r,
                                                             const T* __restrict__ x, const T* __restrict__ y,
@@ -487,6 +490,325 @@ static int resample_typed(mclhip_ctx* c, double r, int algo) {
 int launch_resample(mclhip_ctx* c, double r, int algo) {
   if (c->dtype == MCLHIP_F32) return resample_typed<float>(c, r, algo);
   return resample_typed<double>(c, r, algo);
+}
+
+
+// ===========================================================================
+// The same normalisation + order-exact CDF + search as above in six launches instead of thirteen, for the fused
+// update (mclhip_step*): at 2^20 particles the thirteen kernels are microseconds each and a third of their time is
+// the gaps between them.  Same arithmetic where it is observable: the sum in numpy's order, w / sum, the strictly
+// sequential running sum -- so weights and indices are bit-equal to those of mclhip_normalise + mclhip_resample.
+//   1  max_partial_kernel            (log-weights only)
+//   2  chunk_tile_sum_kernel         w = exp(logw - max); exact sum per 8192-chunk, approximate sum per 2048-tile
+//   3  normalise_classify_kernel     total, w /= total, approximate scan inside the tile, classification, tile aggregates
+//   4  records_kernel                integer prefix + record count per element, irregular records; the block that
+//                                    finishes last replays the records (the one serial step)
+//   5  finalize_cdf_kernel
+//   6  search_gather_kernel
+// ===========================================================================
+constexpr int kMaxFusedChunks = 1024;   // chunk sums are added one by one by every block: beyond this the unfused path is used
+
+template <bool FROM_LOG>
+__global__ __launch_bounds__(512) void chunk_tile_sum_kernel(double* __restrict__ w, int64_t n,
+                                                             double* __restrict__ chunk_sums,
+                                                             double* __restrict__ tile_sums,
+                                                             const double* __restrict__ logw,
+                                                             const double* __restrict__ max_part, int np,
+                                                             double* __restrict__ scal) {
+  __shared__ double wave_sum[8];
+  __shared__ double s_max;
+  const int64_t base = (int64_t)blockIdx.x * kSumChunk;
+  const int cnt = (int)((n - base) < kSumChunk ? (n - base) : kSumChunk);
+  double mx = 0.0;
+  if constexpr (FROM_LOG) {
+    double m = -INFINITY;
+    for (int i = threadIdx.x; i < np; i += blockDim.x) m = fmax(m, max_part[i]);
+    for (int d = 32; d >= 1; d >>= 1) m = fmax(m, __shfl_xor(m, d, 64));
+    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = wave_sum[0];
+      for (int k = 1; k < 8; ++k) t = fmax(t, wave_sum[k]);
+      s_max = t;
+      if (blockIdx.x == 0) scal[1] = t;
+    }
+    __syncthreads();
+    mx = s_max;
+    __syncthreads();
+  }
+  auto weight = [&](int64_t i) -> double {
+    if constexpr (FROM_LOG) {
+      const double v = (mx == -INFINITY) ? 0.0 : exp(logw[i] - mx);
+      w[i] = v;
+      return v;
+    } else {
+      return w[i];
+    }
+  };
+  if (cnt == kSumChunk) {
+    // numpy's pairwise tree for n = 8192 (see chunk_sum_kernel); its nodes of 2048 elements are the tile sums
+    const int leaf = threadIdx.x >> 3, j = threadIdx.x & 7;
+    const int64_t a = base + leaf * 128 + j;
+    double r = weight(a);
+#pragma unroll
+    for (int g = 1; g < 16; ++g) r = r + weight(a + 8 * g);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) r = r + __shfl_xor(r, d, 64);
+    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = r;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double t0 = wave_sum[0] + wave_sum[1], t1 = wave_sum[2] + wave_sum[3];
+      const double t2 = wave_sum[4] + wave_sum[5], t3 = wave_sum[6] + wave_sum[7];
+      chunk_sums[blockIdx.x] = (t0 + t1) + (t2 + t3);
+      double* ts = tile_sums + (size_t)blockIdx.x * 4;
+      ts[0] = t0; ts[1] = t1; ts[2] = t2; ts[3] = t3;
+    }
+  } else {
+    if constexpr (FROM_LOG) {
+      for (int i = threadIdx.x; i < cnt; i += blockDim.x) (void)weight(base + i);
+      __syncthreads();                       // the block's own stores are visible to its threads
+    }
+    if (threadIdx.x == 0) chunk_sums[blockIdx.x] = pairwise<7>(w + base, cnt);
+    // tile sums of the ragged chunk: any order will do (they only feed the approximate scan)
+    const int q = threadIdx.x >> 7, t = threadIdx.x & 127;   // four tiles, 128 threads each (two waves)
+    double r = 0.0;
+    for (int i = q * kScanTile + t; i < (q + 1) * kScanTile && i < cnt; i += 128) r = r + w[base + i];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) r = r + __shfl_xor(r, d, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = r;
+    __syncthreads();
+    if (threadIdx.x < 4 && (int64_t)threadIdx.x * kScanTile < cnt)
+      tile_sums[(size_t)blockIdx.x * 4 + threadIdx.x] = wave_sum[2 * threadIdx.x] + wave_sum[2 * threadIdx.x + 1];
+  }
+}
+
+// classification of one element of the sequential chain (see ClassifyLoader): prev / cur = approximate running sum
+// before / after it
+__device__ inline KF classify_element(int64_t i, double w, double prev, double cur) {
+  if (i == 0) return KF{0ull, 1u};
+  if (w == 0.0) return KF{0ull, 0u};
+  const double delta = (double)(i + 64) * 0x1p-52 * cur;
+  const double lo = prev - delta, hi = cur + delta;
+  if (!(lo >= 0x1p-1000) || !(hi < INFINITY)) return KF{0ull, 1u};
+  const int e = ilogb(lo);
+  if (w < ldexp(1.0, e - 53)) return KF{0ull, 0u};
+  if (ilogb(hi) != e) return KF{0ull, 1u};
+  const double s = ldexp(w, 52 - e);
+  if (s - floor(s) == 0.5) return KF{0ull, 1u};
+  return KF{(unsigned long long)rint(s), 0u};
+}
+
+// What kernels 3 and 4 share: the tile's normalised weights, the approximate running sum at every element (offset =
+// sum of the earlier tiles' sums / total), the classification.  Both kernels run exactly this code on exactly these
+// values, so they classify alike.
+struct TileScan {
+  double wn[kScanItems];
+  KF kf[kScanItems];
+  KF local;        // inclusive scan of the thread's KF sum across the block
+  KF tile_total;
+};
+
+template <bool DIVIDE>
+__device__ inline void scan_tile(TileScan& T, double* __restrict__ w, int64_t n, const double* __restrict__ tile_sums,
+                                 double total) {
+  __shared__ double s_red[4];
+  __shared__ double s_off;
+  // un-normalised weight before this tile: every thread adds a strided share of the earlier tiles' sums
+  double part = 0.0;
+  for (int j = threadIdx.x; j < (int)blockIdx.x; j += kScanBlock) part = part + tile_sums[j];
+  for (int d = 32; d >= 1; d >>= 1) part = part + __shfl_xor(part, d, 64);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) s_off = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) / total;
+  __syncthreads();
+  const double off = s_off;
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  double acc = 0.0;
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j) {
+    double v = 0.0;
+    if (base + j < n) {
+      v = w[base + j];
+      if (DIVIDE) { v = v / total; w[base + j] = v; }   // mc_localization.py:248
+    }
+    T.wn[j] = v;
+    acc = acc + v;
+  }
+  double tot;
+  const double incl = block_incl_scan<double>(acc, &tot);
+  double run = off + (incl - acc);   // approximate running sum before this thread's first element
+  KF ksum = KF{0ull, 0u};
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j) {
+    const double prev = run;
+    run = run + T.wn[j];
+    T.kf[j] = (base + j < n) ? classify_element(base + j, T.wn[j], prev, run) : KF{0ull, 0u};
+    ksum = ksum + T.kf[j];
+  }
+  T.local = block_incl_scan<KF>(ksum, &T.tile_total);
+}
+
+// total of the chunk sums in numpy's order (left to right), by every block for itself
+__device__ inline double total_of_chunks(const double* __restrict__ chunk_sums, int nchunks) {
+  __shared__ double s_chunk[kMaxFusedChunks];
+  __shared__ double s_total;
+  for (int i = threadIdx.x; i < nchunks; i += blockDim.x) s_chunk[i] = chunk_sums[i];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    int i = 0;
+    for (; i + 8 <= nchunks; i += 8) {        // eight reads in flight, then the eight additions in order
+      double v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = s_chunk[i + j];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t = t + v[j];
+    }
+    for (; i < nchunks; ++i) t = t + s_chunk[i];
+    s_total = t;
+  }
+  __syncthreads();
+  return s_total;
+}
+
+__global__ __launch_bounds__(kScanBlock) void normalise_classify_kernel(double* __restrict__ w, int64_t n,
+                                                                        const double* __restrict__ chunk_sums, int nchunks,
+                                                                        const double* __restrict__ tile_sums,
+                                                                        KF* __restrict__ tile_kf, double* __restrict__ scal,
+                                                                        unsigned int* __restrict__ done_counter) {
+  const double total = total_of_chunks(chunk_sums, nchunks);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { scal[0] = total; *done_counter = 0u; }
+  TileScan T;
+  scan_tile<true>(T, w, n, tile_sums, total);
+  if (threadIdx.x == 0) tile_kf[blockIdx.x] = T.tile_total;
+}
+
+__global__ __launch_bounds__(kScanBlock) void records_kernel(double* __restrict__ wn, int64_t n,
+                                                             const double* __restrict__ tile_sums,
+                                                             const KF* __restrict__ tile_kf, const double* __restrict__ scal,
+                                                             unsigned long long* __restrict__ ks, unsigned int* __restrict__ fs,
+                                                             IrrRecord* __restrict__ irr, RunBase* __restrict__ bases,
+                                                             unsigned int* __restrict__ done_counter) {
+  __shared__ KF s_kred[4];
+  __shared__ int s_last;
+  const double total = scal[0];
+  TileScan T;
+  scan_tile<false>(T, wn, n, tile_sums, total);
+  // integer prefix and record count of the earlier tiles (exact, any order)
+  KF part = KF{0ull, 0u};
+  for (int j = threadIdx.x; j < (int)blockIdx.x; j += kScanBlock) part = part + tile_kf[j];
+  for (int d = 32; d >= 1; d >>= 1) part = part + KF{(unsigned long long)__shfl_xor((long long)part.k, d, 64), (unsigned int)__shfl_xor((int)part.f, d, 64)};
+  if ((threadIdx.x & 63) == 0) s_kred[threadIdx.x >> 6] = part;
+  __syncthreads();
+  const KF tile_off = (s_kred[0] + s_kred[1]) + (s_kred[2] + s_kred[3]);
+  KF own_sum = KF{0ull, 0u};
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j) own_sum = own_sum + T.kf[j];
+  KF run = tile_off + KF{T.local.k - own_sum.k, T.local.f - own_sum.f};   // exclusive prefix of this thread
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j) {
+    run = run + T.kf[j];
+    if (base + j < n) {
+      ks[base + j] = run.k;
+      fs[base + j] = run.f;
+      if (T.kf[j].f) {
+        // the records (and their number, below) are read by another block of this launch: agent-scope stores,
+        // which go through to memory, and agent-scope loads on the reading side
+        IrrRecord* dst = irr + (run.f - 1);
+        __hip_atomic_store(&dst->i, base + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<long long*>(&dst->w), __double_as_longlong(T.wn[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&dst->P, run.k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (base + j == n - 1) __hip_atomic_store(done_counter + 1, run.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // number of records
+    }
+  }
+  // The block that finishes last walks the irregular records (the serial step of the method).  Hand-over between
+  // blocks: every wave waits until its stores have left, the block meets, one lane counts the block in; the block
+  // whose count comes last reads what the others stored, with loads that go past the compute unit's own cache.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int before = __hip_atomic_fetch_add(done_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_last = before == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!s_last || threadIdx.x >= 64) return;
+  // replay (see replay_kernel), by the first wavefront of the last block
+  const int lane = threadIdx.x;
+  const unsigned int nirr = __hip_atomic_load(done_counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  double c = 0.0;
+  unsigned long long Pprev = 0ull;
+  int e_run = -1000;
+  for (unsigned int b0 = 0; b0 < nirr; b0 += 64) {
+    const unsigned int cnt = (nirr - b0) < 64u ? (nirr - b0) : 64u;
+    IrrRecord rec = IrrRecord{0, 0.0, 0ull};
+    if ((unsigned)lane < cnt) {
+      const IrrRecord* src = irr + b0 + lane;
+      rec.i = __hip_atomic_load(&src->i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      rec.w = __longlong_as_double(__hip_atomic_load(reinterpret_cast<const long long*>(&src->w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      rec.P = __hip_atomic_load(&src->P, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    RunBase mine = RunBase{0.0, 0ull, -1000, 0};
+    for (unsigned int j = 0; j < cnt; ++j) {
+      const int64_t ii = __shfl((long long)rec.i, (int)j, 64);
+      const double wj = __shfl(rec.w, (int)j, 64);
+      const unsigned long long Pj = (unsigned long long)__shfl((long long)rec.P, (int)j, 64);
+      const double before = c + (double)(Pj - Pprev) * ldexp(1.0, e_run - 52);  // exact
+      c = (ii == 0) ? wj : before + wj;  // the one true float64 addition
+      Pprev = Pj;
+      e_run = (c >= 0x1p-1000 && c < INFINITY) ? ilogb(c) : -1000;
+      if ((unsigned)lane == j) mine = RunBase{c, Pj, e_run, 0};
+    }
+    if ((unsigned)lane < cnt) bases[b0 + lane] = mine;
+  }
+}
+
+template <typename T>
+static int normalise_resample_typed(mclhip_ctx* c, int mode, double r) {
+  const int64_t n = c->M;
+  const int a = c->cur, b = 1 - c->cur;
+  double* w = c->w[a];
+  const unsigned g = (unsigned)((n + 255) / 256);
+  const int nchunks = (int)((n + kSumChunk - 1) / kSumChunk);
+  const int ntile = (int)((n + kScanTile - 1) / kScanTile);
+  double* tile_sums = c->cdf_approx;                              // [ntile] of the [M] array: free in this path
+  unsigned int* done_counter = reinterpret_cast<unsigned int*>(c->scal + 6);
+  if (mode == MCLHIP_W_LOG) {
+    const int np = 1024;
+    hipLaunchKernelGGL(max_partial_kernel, dim3(np), dim3(256), 0, c->stream, c->logw, n, (double*)c->blk_a);
+    hipLaunchKernelGGL(chunk_tile_sum_kernel<true>, dim3(nchunks), dim3(512), 0, c->stream, w, n, c->chunk_sums, tile_sums,
+                       (const double*)c->logw, (const double*)c->blk_a, np, c->scal);
+  } else {
+    hipLaunchKernelGGL(chunk_tile_sum_kernel<false>, dim3(nchunks), dim3(512), 0, c->stream, w, n, c->chunk_sums, tile_sums,
+                       (const double*)nullptr, (const double*)nullptr, 0, c->scal);
+  }
+  hipLaunchKernelGGL(normalise_classify_kernel, dim3(ntile), dim3(kScanBlock), 0, c->stream, w, n,
+                     (const double*)c->chunk_sums, nchunks, (const double*)tile_sums, (KF*)c->blk_b, c->scal, done_counter);
+  hipLaunchKernelGGL(records_kernel, dim3(ntile), dim3(kScanBlock), 0, c->stream, w, n, (const double*)tile_sums,
+                     (const KF*)c->blk_b, (const double*)c->scal, (unsigned long long*)c->kscan, c->fscan,
+                     (IrrRecord*)c->irr, (RunBase*)c->bases, done_counter);
+  hipLaunchKernelGGL(finalize_cdf_kernel, dim3(g), dim3(256), 0, c->stream, (const unsigned long long*)c->kscan,
+                     c->fscan, (const RunBase*)c->bases, n, 0ull, 0u, c->cdf_exact, (const unsigned long long*)nullptr);
+  hipLaunchKernelGGL(search_gather_kernel<T>, dim3(g), dim3(256), 0, c->stream, c->cdf_exact, n, r, (const T*)c->px[a],
+                     (const T*)c->py[a], (const T*)c->pth[a], (const double*)w, (T*)c->px[b], (T*)c->py[b], (T*)c->pth[b],
+                     c->w[b], c->idx);
+  MCL_HIP(c, hipGetLastError());
+  c->cur = b;
+  return MCLHIP_OK;
+}
+
+// normalise + resample for the fused update; falls back to the two separate sequences for very large sets
+int launch_normalise_resample(mclhip_ctx* c, int mode, double r) {
+  const int nchunks = (int)((c->M + kSumChunk - 1) / kSumChunk);
+  if (nchunks > kMaxFusedChunks) {
+    MCL_TRY_W(launch_normalise(c, mode));
+    return launch_resample(c, r, MCLHIP_RESAMPLE_PARALLEL);
+  }
+  if (c->dtype == MCLHIP_F32) return normalise_resample_typed<float>(c, mode, r);
+  return normalise_resample_typed<double>(c, mode, r);
 }
 
 

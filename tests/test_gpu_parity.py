@@ -531,3 +531,38 @@ def test_augmented_mcl_with_device_noise():
     assert ctx.resample_augmented_device(0.3 / M, float("nan"), 15.0, 15.0, 99) == 0
     assert np.array_equal(ctx.get_particles()[0], X[idx])
     ctx.close()
+
+
+@pytest.mark.parametrize("dtype,mode", [(1, 0), (1, 1), (0, 1)])
+def test_fused_step_equals_the_separate_calls(dtype, mode):
+    """mclhip_step (six launches for normalisation + order-exact resampling, the last block of one of them replaying
+    the irregular records) against mclhip_sample / normalise / resample: same weights, same indices, same poses,
+    for particle counts around every tile / chunk boundary and over several steps in a row."""
+    L = _lib()
+    from slam_amd import workload as W
+    grid = W.synthetic_map(256)
+    angles = W.beam_angles(24)
+    rng = np.random.RandomState(17)
+    for M in (1, 63, 500, 2048, 2049, 8191, 8192, 8193, 40000, 1 << 20):
+        X = W.uniform_particles(grid, M, seed=M % 1000 + 3)
+        a = L.Context(0, dtype)
+        b = L.Context(0, dtype)
+        for c in (a, b):
+            c.set_map(grid, W.RES, W.RES)
+            _sensor(c, angles)
+            c.set_particles(X)
+        z = a.raycast(X[0], want_hits=False)[0][0]
+        for t in range(3):
+            noise = rng.randint(-1000, 1001, size=(M, 3, 12)).astype(np.int16) if M <= 40000 else None
+            r = float(rng.rand()) / M
+            a.step(1.5, 0.5 * (t % 2), 0.1, ALPHA, z, r, noise, 50 + t, mode, wait=True)
+            b.shard_sample(1.5, 0.5 * (t % 2), 0.1, ALPHA, z, noise, 50 + t, mode)    # same kernels as the fused step's first half
+            total = b.normalise(mode)
+            idx = b.resample(r)
+            assert np.array_equal(a.get_indices(), idx), (M, t)
+            Xa, wa, _ = a.get_particles()
+            Xb, wb, _ = b.get_particles()
+            assert np.array_equal(Xa, Xb) and np.array_equal(wa, wb), (M, t)
+            assert np.isfinite(total)
+        a.close()
+        b.close()
