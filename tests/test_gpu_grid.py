@@ -133,6 +133,90 @@ def test_more_headings_against_the_oracle(n, n_dir, ut):
     assert np.array_equal(got, want), "%d cells differ" % np.sum(got != want)
 
 
+def _stage_ranges(grid, ii, jj, n_dir, res_theta, angles):
+    """Ranges and hit cells of the device's stage sector query (mclhip_raycast) for the poses the histogram filter
+    predicts from -- cell centres (j*res_x, i*res_y) at every heading -- and the oracle's for the same poses."""
+    from slam_amd import _lib as L
+    sp = O.SensorParams()
+    m = L.Context(0, L.F64)
+    m.set_map(grid, G.RES_X, G.RES_Y)                # obstacle == 0: the same cells as < 200 on a {0, 255} map
+    m.set_sensor(list(angles), sp.z_max, sp.sigma_hit, sp.lambda_short, [sp.w_hit, sp.w_short, sp.w_max, sp.w_rand], HALF)
+    N = len(ii)
+    poses = np.zeros((N, n_dir, 3))
+    poses[:, :, 0] = (jj * G.RES_X)[:, None]
+    poses[:, :, 1] = (ii * G.RES_Y)[:, None]
+    poses[:, :, 2] = np.array([G.heading(d, res_theta) for d in range(n_dir)])[None, :]
+    P = poses.reshape(-1, 3)
+    R_g, H_g = m.raycast(P)
+    m.close()
+    return P, R_g.reshape(N, n_dir, -1), H_g.astype(np.int64).reshape(N, n_dir, -1)
+
+
+def _assert_only_lattice_ties(grid, ii, jj, res_theta, angles, R_g, H_g, R_o, H_o):
+    """Every (cell, heading, beam) whose range differs between device and oracle is decided by ONE obstacle cell that
+    lies exactly on a sector edge: on a row, column or diagonal through the pose cell (integer test) at exactly
+    +-5 degrees from the beam axis.  There the bearing equals the edge to the last bit and atan2's rounding -- which
+    numpy's SIMD path, libm and the device do not share -- decides; everywhere else the two agree.  Returns the count."""
+    W = grid.shape[1]
+    bad = np.argwhere(R_g != R_o)
+    for n, d, k in bad:
+        cid = H_g[n, d, k] if R_g[n, d, k] < R_o[n, d, k] else H_o[n, d, k]     # the cell one side let in and the other did not
+        assert cid >= 0
+        di, dj = cid // W - ii[n], cid % W - jj[n]
+        assert di == 0 or dj == 0 or abs(di) == abs(dj), (n, d, k, di, dj)
+        bearing = np.degrees(np.arctan2(float(np.sign(di)), float(np.sign(dj)))) % 360.0    # a multiple of 45 degrees, exact
+        axis = (angles[k] + d * res_theta) % 360.0
+        off = (axis - bearing) % 360.0
+        assert off in (5.0, 355.0), (n, d, k, axis, bearing)
+    return len(bad)
+
+
+def test_72_headings_unshifted_differ_from_the_oracle_only_at_exact_ties():
+    """The reference's own beam set with 5-degree heading bins, not shifted: sector edges then fall on the grid's
+    axis and diagonal directions and cells exactly on an edge are in or out by the last bit of atan2.  Every
+    difference between device and oracle is shown to be such a tie (and counted); with the tie decisions taken as the
+    device takes them the update is bit-equal to the oracle's."""
+    n, n_dir, res_theta = 22, 72, 5
+    rng = np.random.RandomState(72)
+    grid = np.full((n, n), 255, np.uint8)
+    grid[0, :] = grid[-1, :] = 0
+    grid[:, 0] = grid[:, -1] = 0
+    for _ in range(n // 3):
+        i, j = rng.randint(1, n - 1, 2)
+        if rng.randint(2):
+            grid[i, j:j + rng.randint(2, 9)] = 0
+        else:
+            grid[i:i + rng.randint(2, 9), j] = 0
+    angles = list(G.SENSOR_ANGLES)
+    ii, jj, Z_o = G.predicted_ranges(grid, n_dir, angles=angles, res_theta=res_theta)
+    P, R_g, H_g = _stage_ranges(grid, ii, jj, n_dir, res_theta, angles)
+    lut, cell = O.obstacle_lut(grid)
+    R_o, H_o = O.sector_query_batch(P, lut, cell, angles)
+    R_o, H_o = R_o.reshape(Z_o.shape), H_o.reshape(Z_o.shape)
+    assert np.array_equal(R_o, Z_o)                               # the two oracles agree
+    n_ties = _assert_only_lattice_ties(grid, ii, jj, res_theta, angles, R_g, H_g, R_o, H_o)
+    print("72 headings unshifted, %dx%d map: %d of %d (cell, heading, beam) ranges differ, all exact lattice ties"
+          % (n, n, n_ties, R_o.size))
+    assert 0 < n_ties < 0.02 * R_o.size
+    # the histogram filter's own kernel decides the ties as the stage query does: bit-equal update given those ranges
+    ctx = _ctx(grid, n_dir, res_theta, angles)
+    pred = rng.rand(n, n, n_dir) ** 2
+    pred[grid < 200] = 0
+    z_meas = [0.61, 1.2, 5.0, 2.35, 0.0, 4.99, 3.3, 0.9, 5.0, 1.75, 2.5, 0.3, 4.2]
+    ctx.grid_set_prediction(pred)
+    got_total = ctx.grid_update(z_meas)
+    got = ctx.grid_get_belief()[0]
+    want, total, _ = G.update(pred, grid, z_meas, n_dir, angles=angles, Z=R_g)
+    assert got_total == total
+    assert np.array_equal(got, want), "%d cells differ" % np.sum(got != want)
+    # and against the oracle's own ranges the belief differs only where a tie sits
+    want_o = G.update(pred, grid, z_meas, n_dir, angles=angles, Z=Z_o)[2]
+    raw_g = G.update(pred, grid, z_meas, n_dir, angles=angles, Z=R_g)[2]
+    tied = np.zeros((n, n, n_dir), bool)
+    tied[ii[:, None], jj[:, None], np.arange(n_dir)[None, :]] = np.any(R_g != Z_o, axis=2)
+    assert not np.any((raw_g != want_o) & ~tied)
+
+
 def test_entry_classes_with_negative_and_irregular_angles():
     """Beams below zero (their table angle reaches the reference's test one turn low), beams that no other
     heading shares and beams that coincide across headings only after a full turn: the update on classes of
@@ -201,6 +285,25 @@ def test_full_size_properties():
     assert not pk[~free].any()
     assert np.all(pk >= 0)
     assert abs(float(pk.sum(dtype=np.float64)) - 1.0) < 1e-3   # float32 normalisation of 3e8 terms
+    # a 32x32 window against the oracle: predicted ranges (exact up to lattice ties, see above) and the update
+    i0, j0 = 1000, 700
+    win = np.zeros_like(free)
+    win[i0:i0 + 32, j0:j0 + 32] = True
+    wi, wj = np.nonzero(free & win)
+    assert len(wi) > 500
+    angles = list(G.SENSOR_ANGLES)
+    Pw, R_g, H_g = _stage_ranges(grid, wi, wj, n_dir, 5, angles)
+    lut, cell = O.obstacle_lut(grid)
+    near = (np.abs(lut[:, 0] - (j0 + 16) * G.RES_X) < 8.0) & (np.abs(lut[:, 1] - (i0 + 16) * G.RES_Y) < 8.0)   # 5 m + the window
+    R_o, H_o = O.sector_query_batch(Pw, lut[near], cell[near], angles)
+    R_o, H_o = R_o.reshape(R_g.shape), H_o.reshape(R_g.shape)
+    n_ties = _assert_only_lattice_ties(grid, wi, wj, 5, angles, R_g, H_g, R_o, H_o)
+    print("2048^2 x 72, 32x32 window: %d of %d ranges differ from the oracle, all exact lattice ties" % (n_ties, R_o.size))
+    z_w = [2.0, 3.1, 5.0, 1.2, 0.8, 4.4, 5.0, 2.2, 2.9, 3.3, 5.0, 1.0, 0.6]
+    for d in (0, 17, 71):
+        q, _ = G.cell_likelihood(z_w, R_g[:, d, :])
+        raw = (pp[wi, wj, d] * q).astype(np.float32)                     # robot.py:300
+        assert np.array_equal(pk[wi, wj, d], raw / np.float32(total)), d    # pk /= pk.sum() in float32 (robot.py:308)
     # predict is linear in the belief
     ctx.grid_predict(1.5, 0.5, G.DT, ALPHA)
     a = ctx.grid_get_belief(False, True)[1][512:520, 512:520].copy()
