@@ -278,3 +278,76 @@ def test_one_pose_motion_sampler_and_copies():
     if y.feature:
         z.feature[0].m[0, 0] += 1.0
         assert z.feature[0].m[0, 0] != y.feature[0].m[0, 0]
+
+
+def _read_particles(ctx, which, cap):
+    """Pose, weight and feature list of a few particles of a large set, through the row-packing calls of the
+    multi-GPU exchange (one row per particle) instead of a copy of the whole state."""
+    which = np.asarray(which, np.int64)
+    ctx.fs_set_row_slots(cap)
+    words = ctx.fs_row_words()
+    rows = np.zeros((len(which), words), np.int64)
+    prow = np.zeros((len(which), 5))
+    ctx.shard_pack(which, which + 1, prow.ctypes.data)
+    ctx.fs_shard_pack(which, which + 1, rows.ctypes.data)
+    out = []
+    for k in range(len(which)):
+        y = F.Part()
+        y.x = prow[k, :3].reshape(3, 1).copy()
+        y.w = float(prow[k, 3])
+        n = int(rows[k, 0])
+        y.new_feature_id = int(rows[k, 1])
+        for j in range(n):
+            s = rows[k, 2 + 9 * j: 2 + 9 * (j + 1)]
+            d = s[:7].view(np.float64)
+            f = F.Feat(np.array([[d[0]], [d[1]]]), np.array([[d[2], d[3]], [d[4], d[5]]]))
+            f.w, f.i, f.id = float(d[6]), int(s[7]), int(s[8])
+            y.feature.append(f)
+        out.append(y)
+    return out
+
+
+def test_large_configuration_subset_against_the_oracle():
+    """2^20 particles x 256 landmarks (about 64 sensed per step, feature lists of 80+), the configuration that is
+    timed: three steps with device-drawn numbers (ancestor indices checked against the sequential walk on the device's
+    own weights), then one per-particle update with pre-drawn numbers for every particle, of which 64 particles are
+    compared with the oracle run from the state the device itself held before that update."""
+    from slam_amd import _lib as L
+    M, nl, cap = 1 << 20, 256, 320
+    rng = np.random.RandomState(9)
+    lm = np.stack([rng.uniform(-8, 33, nl), rng.uniform(-24, 8, nl), np.zeros(nl)], 1).astype(np.float32)
+    ctx = L.Context(0, L.F64)
+    ctx.fs_init(M, cap)
+    ctx.shard_set(0, M)
+    x_gt = [0, 0, 0]
+    for t in range(3):
+        ut = [25, 0.001]
+        x_gt = F.true_pose_step(x_gt, ut)
+        tr, tp, tv = _truth(x_gt, lm)
+        idx = ctx.fs_step(ut[0], ut[1], F.DT, F.ALPHA, tr, tp, tv, None, None, (0.2 + 0.3 * t) / M, seed=40 + t, want_idx=True)
+        assert idx.min() >= 0 and idx.max() <= M - 1 and np.all(np.diff(idx) >= 0)
+    # the state every particle-update below starts from, as the device holds it
+    pick = np.sort(rng.choice(M, 64, replace=False))
+    before = _read_particles(ctx, pick, cap)
+    assert min(len(y.feature) for y in before) > 40
+    ut = [25, -np.pi / 2 * 5]
+    x_gt = F.true_pose_step(x_gt, ut)
+    tr, tp, tv = _truth(x_gt, lm)
+    truth = F.true_measurements(x_gt, lm)
+    nv = int(tv.sum())
+    assert nv > 40
+    ints = rng.randint(-1000, 1000, size=(M, 3, 12)).astype(np.int16)
+    normals = rng.randn(M, 2 * nv)
+    ctx.fs_shard_kernel(ut[0], ut[1], F.DT, F.ALPHA, tr, tp, tv, ints, normals)      # fast_slam1.py:246-404 for every particle
+    after = _read_particles(ctx, pick, cap)
+    for k, m in enumerate(pick):
+        y = before[k]
+        F.particle_step(y, ut, ints[m], normals[m], truth)
+        g = after[k]
+        assert len(g.feature) == len(y.feature) and g.new_feature_id == y.new_feature_id, m
+        assert rel_err(g.x[:, 0], y.x[:, 0]) < 1e-12 and rel_err([g.w], [y.w]) < 1e-11, m
+        for fg, fo in zip(g.feature, y.feature):
+            assert (fg.i, fg.id) == (fo.i, fo.id), m
+            assert rel_err(fg.m, fo.m) < 1e-12 and rel_err([fg.w], [fo.w]) < 1e-11, m
+            assert np.all(np.abs(fg.Cov - fo.Cov) <= 1e-11 * np.max(np.abs(fo.Cov))), m
+    ctx.close()
