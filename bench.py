@@ -341,6 +341,10 @@ def main():
                                     ("device-driven exchange" if filt.device_path else "host-combined exchange"))
                        if filt.collective else "single GPU"},
             "roofline": roofline(a, M, B, ray_ms, n_ray, copy_gbs),
+            "exchange": ({"rows_per_step_this_rank": filt.rows_sent_total / max(filt.steps_done, 1),
+                          "bytes_between_ranks_per_step_this_rank": 48.0 * filt.rows_sent_off_rank / max(filt.steps_done, 1),
+                          "note": "only rows that some position draws travel (48 B each); one host read per step (the split sizes)"}
+                         if filt.device_path else None),
             "kernel_ms": {"raycast": ray_ms, "motion": ms_mot / max(n_mot, 1),
                           "normalise+resample+gather": ms_res / max(n_res, 1)},
         }

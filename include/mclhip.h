@@ -272,7 +272,8 @@ int mclhip_shard_unpack_resample(mclhip_ctx* ctx, const void* rows, int64_t L, d
  * (it is single-process).  Same arithmetic as the mclhip_shard_* calls above, but
  * every call only enqueues on the context's stream and exchanges data through
  * DEVICE pointers (e.g. torch tensors that RCCL collectives read and write), so a
- * whole step needs one device-to-host read.  Log-weight mode only.
+ * whole step needs one device-to-host read (the row counts that size the exchange).
+ * Only rows that some position draws travel.  Log-weight mode only.
  * firsts [world + 1]: global index of every rank's first particle, firsts[world]
  * = total.  cap: irregular records per rank that fit the exchange block of
  * 16 + 24 * cap bytes. */
@@ -290,13 +291,18 @@ int mclhip_dshard_weights(mclhip_ctx* ctx, const double* d_gmax, double* d_chunk
 int mclhip_dshard_scan(mclhip_ctx* ctx, const double* d_all_chunks, const int64_t* firsts, int world, int rank,
                        void* d_records_out, int cap);
 /* d_all_records [world][16 + 24*cap bytes]: global record list, exact local running
- * sums; d_counts_out [2*world + 1]: local counts below U of every rank's first and
- * last position (to be summed over ranks), last entry = 1 if a rank overflowed cap. */
+ * sums; then which local rows are drawn at all (mc_localization.py:253-259 reads X[i]
+ * only for the drawn i) and by the positions of which rank.  d_counts_out [world + 1]:
+ * number of rows this rank sends to every rank, last entry = 1 if a rank overflowed cap. */
 int mclhip_dshard_finalize(mclhip_ctx* ctx, const void* d_all_records, const int64_t* firsts, int world, int rank,
                            int cap, double r, int64_t* d_counts_out);
-/* as mclhip_shard_pack / mclhip_shard_unpack_resample, rows on the device, no wait. */
-int mclhip_dshard_pack(mclhip_ctx* ctx, const int64_t* lo, const int64_t* hi, int nslices, void* d_rows);
-int mclhip_dshard_unpack_resample(mclhip_ctx* ctx, const void* d_rows, int64_t L, double r, int64_t row0_global);
+/* The drawn rows for rank 0, then for rank 1, ... (d_counts_out[d] rows each) into d_rows:
+ * six doubles per row -- x, y, theta, w, running sum, global index (as int64 bits). */
+int mclhip_dshard_pack(mclhip_ctx* ctx, int world, void* d_rows);
+/* Resamples the local positions from the L received rows (all sources, ascending global
+ * index): ancestor = first row whose running sum is not below r + m/M_total, the last row
+ * if there is none; gathers pose and weight.  No wait. */
+int mclhip_dshard_unpack_resample(mclhip_ctx* ctx, const void* d_rows, int64_t L, double r);
 /* Ancestor indices of the last resampling (waits for the stream). */
 int mclhip_get_indices(mclhip_ctx* ctx, int64_t* idx_out);
 

@@ -81,8 +81,8 @@ PROTOTYPES = {
     "mclhip_dshard_scan": (C.c_int, [_ctx_p, C.c_void_p, _i64_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "mclhip_dshard_finalize": (C.c_int, [_ctx_p, C.c_void_p, _i64_p, C.c_int, C.c_int, C.c_int, C.c_double,
                                          C.c_void_p]),
-    "mclhip_dshard_pack": (C.c_int, [_ctx_p, _i64_p, _i64_p, C.c_int, C.c_void_p]),
-    "mclhip_dshard_unpack_resample": (C.c_int, [_ctx_p, C.c_void_p, C.c_int64, C.c_double, C.c_int64]),
+    "mclhip_dshard_pack": (C.c_int, [_ctx_p, C.c_int, C.c_void_p]),
+    "mclhip_dshard_unpack_resample": (C.c_int, [_ctx_p, C.c_void_p, C.c_int64, C.c_double]),
     "mclhip_get_indices": (C.c_int, [_ctx_p, _i64_p]),
     "mclhip_grid_set_map": (C.c_int, [_ctx_p, _u8_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]),
     "mclhip_grid_set_sensor": (C.c_int, [_ctx_p, _dbl_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
@@ -440,14 +440,11 @@ class Context:
         self._ck(self.lib.mclhip_dshard_finalize(self.h, C.c_void_p(d_all_records), _p(f, _i64_p), len(f) - 1, int(rank),
                                                  int(cap), float(r), C.c_void_p(d_counts)), "mclhip_dshard_finalize")
 
-    def dshard_pack(self, lo, hi, d_rows):
-        lo = np.ascontiguousarray(lo, np.int64)
-        hi = np.ascontiguousarray(hi, np.int64)
-        self._ck(self.lib.mclhip_dshard_pack(self.h, _p(lo, _i64_p), _p(hi, _i64_p), len(lo), C.c_void_p(d_rows)),
-                 "mclhip_dshard_pack")
+    def dshard_pack(self, world, d_rows):
+        self._ck(self.lib.mclhip_dshard_pack(self.h, int(world), C.c_void_p(d_rows)), "mclhip_dshard_pack")
 
-    def dshard_unpack_resample(self, d_rows, L, r, row0_global):
-        self._ck(self.lib.mclhip_dshard_unpack_resample(self.h, C.c_void_p(d_rows), int(L), float(r), int(row0_global)),
+    def dshard_unpack_resample(self, d_rows, L, r):
+        self._ck(self.lib.mclhip_dshard_unpack_resample(self.h, C.c_void_p(d_rows), int(L), float(r)),
                  "mclhip_dshard_unpack_resample")
 
     def get_indices(self):

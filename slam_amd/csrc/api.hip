@@ -300,7 +300,7 @@ using namespace mcl;
 
 extern "C" {
 
-int mclhip_abi_version(void) { return 1; }
+int mclhip_abi_version(void) { return 2; }
 
 int mclhip_device_count(void) {
   int n = 0;
@@ -1106,28 +1106,22 @@ int mclhip_dshard_finalize(mclhip_ctx* c, const void* d_all_records, const int64
   return MCLHIP_OK;
 }
 
-int mclhip_dshard_pack(mclhip_ctx* c, const int64_t* lo, const int64_t* hi, int nslices, void* d_rows) {
+int mclhip_dshard_pack(mclhip_ctx* c, int world, void* d_rows) {
   MCL_TRY(use(c));
   MCL_TRY(need(c, false, false, true));
-  if (!lo || !hi || nslices <= 0) return fail(c, MCLHIP_E_ARG, "lo/hi NULL or no slices");
-  int64_t off = 0;
+  if (!d_rows || world < 1 || world > 64) return fail(c, MCLHIP_E_ARG, "d_rows NULL or world outside 1..64");
   span_begin(c, c->spans, 2);
-  for (int s = 0; s < nslices; ++s) {
-    if (lo[s] < 0 || hi[s] > c->M || hi[s] < lo[s]) return fail(c, MCLHIP_E_ARG, "slice outside the local range");
-    if (hi[s] > lo[s] && !d_rows) return fail(c, MCLHIP_E_ARG, "d_rows is NULL");
-    MCL_TRY(launch_pack_rows(c, lo[s], hi[s], (double*)d_rows + off * 5));
-    off += hi[s] - lo[s];
-  }
+  MCL_TRY(launch_pack_drawn(c, world, (double*)d_rows));
   span_end(c, c->spans);
   return MCLHIP_OK;
 }
 
-int mclhip_dshard_unpack_resample(mclhip_ctx* c, const void* d_rows, int64_t L, double r, int64_t row0_global) {
+int mclhip_dshard_unpack_resample(mclhip_ctx* c, const void* d_rows, int64_t L, double r) {
   MCL_TRY(use(c));
   MCL_TRY(need(c, false, false, true));
   if (!d_rows || L <= 0) return fail(c, MCLHIP_E_ARG, "d_rows NULL or empty");
   span_begin(c, c->spans, 2);
-  MCL_TRY(launch_unpack_resample(c, (const double*)d_rows, L, c->first_index, c->m_total, r, row0_global));
+  MCL_TRY(launch_unpack_drawn(c, (const double*)d_rows, L, r));
   span_end(c, c->spans);
   return MCLHIP_OK;
 }

@@ -269,6 +269,8 @@ int launch_dshard_finalize(mclhip_ctx* c, const void* d_all_rec, const ShardLayo
 int launch_shard_finalize(mclhip_ctx* c, const void* d_records, int64_t nrec, void* d_bases, uint64_t P_off,
                           uint32_t F_off, const unsigned long long* d_meta = nullptr);
 int launch_count_below(mclhip_ctx* c, const double* d_U, int nu, int64_t* d_counts);
+int launch_pack_drawn(mclhip_ctx* c, int world, double* d_dst);
+int launch_unpack_drawn(mclhip_ctx* c, const double* d_rows, int64_t L, double r);
 int launch_pack_rows(mclhip_ctx* c, int64_t lo, int64_t hi, double* d_dst);
 int launch_unpack_resample(mclhip_ctx* c, const double* d_rows, int64_t L, int64_t first_index, int64_t m_total,
                            double r, int64_t row0_global);

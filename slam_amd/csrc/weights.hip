@@ -183,8 +183,10 @@ __device__ inline double shfl_up_v(double v, int d) { return __shfl_up(v, d, 64)
 __device__ inline KF shfl_up_v(const KF& v, int d) {
   return KF{(unsigned long long)__shfl_up((long long)v.k, d, 64), (unsigned int)__shfl_up((int)v.f, d, 64)};
 }
+__device__ inline unsigned int shfl_up_v(unsigned int v, int d) { return (unsigned int)__shfl_up((int)v, d, 64); }
 __device__ inline double zero_of(double*) { return 0.0; }
 __device__ inline KF zero_of(KF*) { return KF{0ull, 0u}; }
+__device__ inline unsigned int zero_of(unsigned int*) { return 0u; }
 
 // inclusive scan of one value per thread across a 256-thread block; returns the block total
 template <typename V>
@@ -967,23 +969,138 @@ __global__ void merge_records_kernel(const unsigned long long* __restrict__ all,
   }
 }
 
-// counts[2d], counts[2d+1] = local running sums below U of the first / last position of rank d
-// (U = r + m / M, mc_localization.py:254); counts[2*world] = the overflow flag of the merge
-__global__ void count_edges_kernel(const double* __restrict__ cdf, int64_t n, double r, ShardLayout lay,
-                                   int64_t m_total, const unsigned long long* __restrict__ meta,
-                                   int64_t* __restrict__ counts) {
-  const int j = threadIdx.x;
-  if (j == 2 * lay.world) { counts[j] = (int64_t)meta[3]; return; }
-  if (j > 2 * lay.world) return;
-  const int d = j >> 1;
-  const int64_t m = (j & 1) ? lay.first[d + 1] - 1 : lay.first[d];
-  const double u = r + ((double)m / (double)m_total);
-  int64_t lo = 0, hi = n;
+// ---- which rows travel: only those that some position draws --------------------------------------------------
+// Position m draws the row i(m) = number of running sums below U_m, U_m = r + m / M (mc_localization.py:254-257).
+// Seen from a row with running sum c: the positions that draw it end where U_m first exceeds c.  first_above(c) is
+// that position, found with the very comparison the walk uses, so that source and destination agree to the bit.
+__device__ inline double position_u(int64_t m, int64_t m_total, double r) { return r + ((double)m / (double)m_total); }
+
+__device__ inline int64_t first_above(double c, int64_t m_total, double r) {
+  // first m in [0, m_total] with U_m > c (m_total if none; also for NaN, which nothing exceeds)
+  int64_t lo = 0, hi = m_total;
+  const double est = (c - r) * (double)m_total;            // U is monotone in m: a bracket around the estimate, checked
+  if (est > -4.0 && est < (double)m_total + 4.0) {
+    int64_t a = (int64_t)est - 2, b = (int64_t)est + 3;
+    a = a < 0 ? 0 : (a > m_total ? m_total : a);
+    b = b < 0 ? 0 : (b > m_total ? m_total : b);
+    const bool lo_ok = (a == 0) || !(position_u(a - 1, m_total, r) > c);
+    const bool hi_ok = (b == m_total) || (position_u(b, m_total, r) > c);
+    if (lo_ok && hi_ok) { lo = a; hi = b; }
+  }
   while (lo < hi) {
     const int64_t mid = (lo + hi) >> 1;
-    if (u > cdf[mid]) lo = mid + 1; else hi = mid;
+    if (position_u(mid, m_total, r) > c) hi = mid; else lo = mid + 1;
   }
-  counts[j] = lo;
+  return lo;
+}
+
+// G[j] = first position beyond those that can draw local row j or an earlier one; the globally last row keeps every
+// position to the end (indices past the end are clamped to it)
+__global__ void draw_ends_kernel(const double* __restrict__ cdf, int64_t n, int64_t m_total, double r, int last_rank,
+                                 int64_t* __restrict__ G) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  G[j] = (last_rank && j == n - 1) ? m_total : first_above(cdf[j], m_total, r);
+}
+
+// local row j is drawn iff some position lies in [G[j-1], G[j]); whether the first local row is drawn depends on the
+// previous rank's last running sum, which is not known here: it always counts as drawn (one row too many at worst)
+struct DrawnFlagLoader {
+  const int64_t* G;
+  __device__ unsigned int operator()(int64_t j) const { return (j == 0 || G[j] > G[j - 1]) ? 1u : 0u; }
+};
+struct StoreU32 {
+  unsigned int* p;
+  __device__ void operator()(int64_t i, unsigned int incl, unsigned int) const { p[i] = incl; }
+};
+
+// slices[4d .. 4d+3] = first row, last row (local; first > last: none), number of drawn rows among them, and where
+// they start in the send buffer, for destination rank d; counts[d] = that number, counts[world] = the overflow flag
+// of the record merge.  Destination d owns the positions [first[d], first[d+1]); it needs the rows j with
+// G[j] > first[d] (some position of d at or after the row's first drawer... its range ends beyond d's start) and
+// G[j-1] <= last position of d.
+__global__ void plan_slices_kernel(const int64_t* __restrict__ G, const unsigned int* __restrict__ S, int64_t n,
+                                   ShardLayout lay, const unsigned long long* __restrict__ meta,
+                                   int64_t* __restrict__ slices, int64_t* __restrict__ counts) {
+  __shared__ int64_t s_cnt[64];
+  const int d = threadIdx.x;
+  if (d < lay.world) {
+    auto first_row_above = [&](int64_t x) -> int64_t {      // first j with G[j] > x (n if none)
+      int64_t lo = 0, hi = n;
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (G[mid] > x) hi = mid; else lo = mid + 1;
+      }
+      return lo;
+    };
+    const int64_t jl = first_row_above(lay.first[d]);
+    int64_t jh = first_row_above(lay.first[d + 1] - 1);      // G[j-1] <= last position  <=>  j <= that row
+    if (jh > n - 1) jh = n - 1;
+    int64_t cnt = 0;
+    if (lay.first[d + 1] > lay.first[d] && jl <= jh) cnt = (int64_t)S[jh] - (jl > 0 ? (int64_t)S[jl - 1] : 0);
+    slices[4 * d] = jl; slices[4 * d + 1] = jh; slices[4 * d + 2] = cnt;
+    s_cnt[d] = cnt;
+    counts[d] = cnt;
+  }
+  __syncthreads();
+  if (d == 0) {
+    int64_t off = 0;
+    for (int k = 0; k < lay.world; ++k) { slices[4 * k + 3] = off; off += s_cnt[k]; }
+    counts[lay.world] = (int64_t)meta[3];
+  }
+}
+
+// rows of six doubles (x, y, theta, w, running sum, global index) of the drawn local rows, destination after
+// destination; a row that positions of two ranks draw goes to both
+template <typename T>
+__global__ __launch_bounds__(256) void pack_drawn_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ th,
+                                                         const double* __restrict__ w, const double* __restrict__ cdf,
+                                                         const int64_t* __restrict__ G, const unsigned int* __restrict__ S,
+                                                         int64_t n, int64_t first_index, int world,
+                                                         const int64_t* __restrict__ slices, double* __restrict__ dst) {
+  __shared__ int64_t s_sl[4 * 64];
+  for (int k = threadIdx.x; k < 4 * world; k += blockDim.x) s_sl[k] = slices[k];
+  __syncthreads();
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  if (!(j == 0 || G[j] > G[j - 1])) return;
+  const int64_t sj = (int64_t)S[j];
+  for (int d = 0; d < world; ++d) {                          // a handful of ranks; the slices ascend with d
+    const int64_t jl = s_sl[4 * d], jh = s_sl[4 * d + 1];
+    if (s_sl[4 * d + 2] == 0 || j < jl || j > jh) continue;
+    const int64_t pos = s_sl[4 * d + 3] + (sj - (jl > 0 ? (int64_t)S[jl - 1] : 0)) - 1;
+    double* row = dst + pos * 6;
+    row[0] = (double)x[j];
+    row[1] = (double)y[j];
+    row[2] = (double)th[j];
+    row[3] = w[j];
+    row[4] = cdf[j];
+    row[5] = __longlong_as_double((long long)(first_index + j));
+  }
+}
+
+// resample this rank's positions from the received rows (all sources, ascending global index): the ancestor is the
+// first row whose running sum is not below U_m, the last row if there is none (the clamp of the single-GPU walk)
+template <typename T>
+__global__ __launch_bounds__(256) void unpack_drawn_kernel(const double* __restrict__ rows, int64_t L, int64_t first_index,
+                                                           int64_t m_total, int64_t n, double r, T* __restrict__ x2,
+                                                           T* __restrict__ y2, T* __restrict__ th2, double* __restrict__ w2,
+                                                           int64_t* __restrict__ idx) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const double U = position_u(first_index + j, m_total, r);
+  int64_t lo = 0, hi = L;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (U > rows[mid * 6 + 4]) lo = mid + 1; else hi = mid;
+  }
+  if (lo > L - 1) lo = L - 1;
+  const double* s = rows + lo * 6;
+  idx[j] = (int64_t)__double_as_longlong(s[5]);
+  x2[j] = (T)s[0];
+  y2[j] = (T)s[1];
+  th2[j] = (T)s[2];
+  w2[j] = s[3];
 }
 
 int launch_dshard_scan(mclhip_ctx* c, const double* d_all_chunks, const ShardLayout& lay, void* d_rec_out, int cap) {
@@ -1001,9 +1118,59 @@ int launch_dshard_finalize(mclhip_ctx* c, const void* d_all_rec, const ShardLayo
   hipLaunchKernelGGL(merge_records_kernel, dim3(1), dim3(256), 0, c->stream, (const unsigned long long*)d_all_rec,
                      lay.world, lay.rank, cap, (IrrRecord*)c->g_records, meta);
   MCL_TRY_W(launch_shard_finalize(c, c->g_records, 0, c->g_bases, 0, 0, meta));
-  hipLaunchKernelGGL(count_edges_kernel, dim3(1), dim3(256), 0, c->stream, c->cdf_exact, c->M, r, lay, c->m_total,
-                     meta, d_counts);
+  // which local rows are drawn at all, and by the positions of which rank: only those travel
+  const int64_t n = c->M;
+  const unsigned g = (unsigned)((n + 255) / 256);
+  const int ntile = (int)((n + kScanTile - 1) / kScanTile);
+  int64_t* G = reinterpret_cast<int64_t*>(c->kscan);           // the integer prefixes are spent once the running sums exist
+  unsigned int* S = c->fscan;                                  // likewise the record counts
+  hipLaunchKernelGGL(draw_ends_kernel, dim3(g), dim3(256), 0, c->stream, (const double*)c->cdf_exact, n, c->m_total, r,
+                     lay.rank == lay.world - 1 ? 1 : 0, G);
+  DrawnFlagLoader fl{G};
+  StoreU32 su{S};
+  hipLaunchKernelGGL((scan_reduce_kernel<unsigned int, DrawnFlagLoader>), dim3(ntile), dim3(kScanBlock), 0, c->stream, fl, n,
+                     (unsigned int*)c->blk_a);
+  hipLaunchKernelGGL((scan_blocks_kernel<unsigned int>), dim3(1), dim3(kScanBlock), 0, c->stream, (unsigned int*)c->blk_a, ntile);
+  hipLaunchKernelGGL((scan_apply_kernel<unsigned int, DrawnFlagLoader, StoreU32>), dim3(ntile), dim3(kScanBlock), 0, c->stream, fl,
+                     su, n, (const unsigned int*)c->blk_a);
+  int64_t* slices = c->small_i + 8;                            // [4 * world] behind the merge's four words
+  hipLaunchKernelGGL(plan_slices_kernel, dim3(1), dim3(64), 0, c->stream, (const int64_t*)G, (const unsigned int*)S, n, lay,
+                     (const unsigned long long*)meta, slices, d_counts);
   MCL_HIP(c, hipGetLastError());
+  return MCLHIP_OK;
+}
+
+// the drawn rows of every destination, one after the other, into d_dst (six doubles per row)
+int launch_pack_drawn(mclhip_ctx* c, int world, double* d_dst) {
+  const int64_t n = c->M;
+  const int a = c->cur;
+  const unsigned g = (unsigned)((n + 255) / 256);
+  const int64_t* G = reinterpret_cast<const int64_t*>(c->kscan);
+  const int64_t* slices = c->small_i + 8;
+  if (c->dtype == MCLHIP_F32)
+    hipLaunchKernelGGL(pack_drawn_kernel<float>, dim3(g), dim3(256), 0, c->stream, (const float*)c->px[a], (const float*)c->py[a],
+                       (const float*)c->pth[a], (const double*)c->w[a], (const double*)c->cdf_exact, G, (const unsigned int*)c->fscan,
+                       n, c->first_index, world, slices, d_dst);
+  else
+    hipLaunchKernelGGL(pack_drawn_kernel<double>, dim3(g), dim3(256), 0, c->stream, (const double*)c->px[a], (const double*)c->py[a],
+                       (const double*)c->pth[a], (const double*)c->w[a], (const double*)c->cdf_exact, G, (const unsigned int*)c->fscan,
+                       n, c->first_index, world, slices, d_dst);
+  MCL_HIP(c, hipGetLastError());
+  return MCLHIP_OK;
+}
+
+int launch_unpack_drawn(mclhip_ctx* c, const double* d_rows, int64_t L, double r) {
+  const int64_t n = c->M;
+  const int b = 1 - c->cur;
+  const unsigned g = (unsigned)((n + 255) / 256);
+  if (c->dtype == MCLHIP_F32)
+    hipLaunchKernelGGL(unpack_drawn_kernel<float>, dim3(g), dim3(256), 0, c->stream, d_rows, L, c->first_index, c->m_total, n, r,
+                       (float*)c->px[b], (float*)c->py[b], (float*)c->pth[b], c->w[b], c->idx);
+  else
+    hipLaunchKernelGGL(unpack_drawn_kernel<double>, dim3(g), dim3(256), 0, c->stream, d_rows, L, c->first_index, c->m_total, n, r,
+                       (double*)c->px[b], (double*)c->py[b], (double*)c->pth[b], c->w[b], c->idx);
+  MCL_HIP(c, hipGetLastError());
+  c->cur = b;
   return MCLHIP_OK;
 }
 

@@ -217,7 +217,11 @@ class ShardedFilter:
         self.t_all_chunks = torch.zeros(W * cmax, dtype=torch.float64, device=dev)
         self.t_rec = torch.zeros(rb, dtype=torch.int64, device=dev)
         self.t_all_rec = torch.zeros(W * rb, dtype=torch.int64, device=dev)
-        self.t_counts = torch.zeros(2 * W + 1, dtype=torch.int64, device=dev)
+        self.t_counts = torch.zeros(W + 1, dtype=torch.int64, device=dev)            # rows for every rank + overflow flag
+        self.t_all_counts = torch.zeros(W * (W + 1), dtype=torch.int64, device=dev)
+        self.rows_sent_off_rank = 0        # running totals, for reports
+        self.rows_sent_total = 0
+        self.steps_done = 0
         self._torch = torch
         self._keep = None
         if self.stream is not None:
@@ -225,7 +229,7 @@ class ShardedFilter:
 
     def _device_step(self, v, omega, dt, alpha, z_meas, r, seed, noise_ints):
         """Generator: enqueues this rank's work and yields the exchanges it needs, in order --
-        ("all_reduce_max", t), ("all_gather", out, inp), ("all_reduce_sum_read", t) -> numpy,
+        ("all_reduce_max", t), ("all_gather", out, inp), ("all_gather_read", out, inp) -> numpy,
         ("all_to_all", send, send_counts, recv_counts) -> recv.  Returns False if a rank had more
         irregular records than the fixed exchange holds (the caller then finishes on the host path)."""
         ctx, rank, world, cap = self.b.ctx, self.rank, self.world, self.RECORD_CAP
@@ -236,16 +240,23 @@ class ShardedFilter:
         ctx.dshard_scan(self.t_all_chunks.data_ptr(), self.firsts, rank, self.t_rec.data_ptr(), cap)
         yield ("all_gather", self.t_all_rec, self.t_rec)
         ctx.dshard_finalize(self.t_all_rec.data_ptr(), self.firsts, rank, cap, r, self.t_counts.data_ptr())
-        counts = yield ("all_reduce_sum_read", self.t_counts)
-        if counts[-1] > 0:
+        # the one host read of the step: how many rows every rank sends to every other (only rows that some
+        # position draws travel; the all-to-all needs its split sizes on the host)
+        counts = yield ("all_gather_read", self.t_all_counts, self.t_counts)
+        counts = counts.reshape(world, world + 1)
+        if counts[:, -1].any():
             return False
-        gidx = np.minimum(counts[:-1], self.m_total - 1)
-        lo, hi, send_counts, recv_counts, glo = self._plan(gidx)
-        send = self._torch.empty((max(sum(send_counts), 1), 5), dtype=self._torch.float64, device=self.t_max.device)
-        if sum(send_counts):
-            ctx.dshard_pack(lo, hi, send.data_ptr())
+        send_counts = [int(c) for c in counts[rank, :world]]
+        recv_counts = [int(c) for c in counts[:world, rank]]
+        n_send, L = sum(send_counts), sum(recv_counts)
+        self.steps_done += 1
+        self.rows_sent_total += n_send
+        self.rows_sent_off_rank += n_send - send_counts[rank]
+        send = self._torch.empty((max(n_send, 1), 6), dtype=self._torch.float64, device=self.t_max.device)
+        if n_send:
+            ctx.dshard_pack(world, send.data_ptr())
         recv = yield ("all_to_all", send, send_counts, recv_counts)
-        ctx.dshard_unpack_resample(recv.data_ptr(), int(sum(recv_counts)), r, int(glo[rank]))
+        ctx.dshard_unpack_resample(recv.data_ptr(), L, r)
         self._keep = (send, recv)       # alive until the next step has been enqueued behind them
         return True
 
@@ -281,12 +292,12 @@ class ShardedFilter:
                         dist.all_reduce(req[1], op=dist.ReduceOp.MAX)
                     elif op == "all_gather":
                         dist.all_gather_into_tensor(req[1], req[2])
-                    elif op == "all_reduce_sum_read":
-                        dist.all_reduce(req[1], op=dist.ReduceOp.SUM)
+                    elif op == "all_gather_read":
+                        dist.all_gather_into_tensor(req[1], req[2])
                         val = req[1].cpu().numpy()
                     elif op == "all_to_all":
                         send, sc, rc = req[1], req[2], req[3]
-                        val = torch.empty((max(int(sum(rc)), 1), 5), dtype=torch.float64, device=send.device)
+                        val = torch.empty((max(int(sum(rc)), 1), send.shape[1]), dtype=torch.float64, device=send.device)
                         dist.all_to_all_single(val[:int(sum(rc))], send[:int(sum(sc))], [int(c) for c in rc],
                                                [int(c) for c in sc])
                     req = gen.send(val)

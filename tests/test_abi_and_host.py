@@ -39,7 +39,7 @@ def test_ctypes_table_matches_header():
     from slam_amd import _lib
     assert sorted(_lib.PROTOTYPES) == _declared()
     lib = _lib.load()
-    assert lib.mclhip_abi_version() == 1
+    assert lib.mclhip_abi_version() == 2
 
 
 def test_no_device_is_a_loud_error():

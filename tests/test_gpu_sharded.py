@@ -14,9 +14,11 @@ ALPHA = [4, 2, 4, 4, 4, 2]
 ANGLES = [0, 15, 30, 45, 60, 75, 90, 345, 330, 315, 300, 285, 270]
 
 
-def _setup(dtype):
+def _setup(dtype, flat=False):
     from slam_amd import _lib
     grid = np.load(os.path.join(GOLDEN, "grid_map_g.npy"))
+    if flat:
+        grid = np.full_like(grid, 255)          # no obstacle: every particle on the map gets the same weight
     ctx = _lib.Context(0, dtype)
     ctx.set_map(grid, 0.15, 0.15)
     w4 = np.array([0.97, 0.005, 0.020, 0.005])
@@ -103,7 +105,7 @@ def test_rccl_path_with_device_tensors_on_one_rank(device_path):
     assert np.array_equal(res["X"], Xr) and np.array_equal(res["w"], wr)
 
 
-def _lockstep_fn(rank, world, dist, sizes, z_meas, record_cap):
+def _lockstep_fn(rank, world, dist, sizes, z_meas, record_cap, flat=False):
     """Several ranks of the device-driven step inside ONE process (one context per rank on the same
     GPU); the exchanges between them are done here with plain tensor operations, so that the
     device kernels that combine the ranks' data see real multi-rank inputs."""
@@ -118,7 +120,7 @@ def _lockstep_fn(rank, world, dist, sizes, z_meas, record_cap):
     filt, gens, req = [], [], []
     for k in range(W):
         first = sum(sizes[:k])
-        ctx = _setup(_lib.F32)
+        ctx = _setup(_lib.F32, flat)
         ctx.set_particles(X[first:first + sizes[k]])
         f = ShardedFilter.for_layout(ctx, k, sizes)
         filt.append(f)
@@ -143,15 +145,15 @@ def _lockstep_fn(rank, world, dist, sizes, z_meas, record_cap):
             cat = torch.cat([q[2] for q in req])
             for q in req:
                 q[1].copy_(cat)
-        elif op == "all_reduce_sum_read":
-            tot = torch.stack([q[1] for q in req]).sum(0)
-            vals = [tot.cpu().numpy() for _ in req]
+        elif op == "all_gather_read":
+            cat = torch.cat([q[2] for q in req])
+            vals = [cat.cpu().numpy() for _ in req]
         elif op == "all_to_all":
             offs = [np.concatenate([[0], np.cumsum(q[2])]).astype(int) for q in req]
             for d in range(W):
                 parts = [req[s][1][offs[s][d]:offs[s][d + 1]] for s in range(W)]
                 assert [len(p) for p in parts] == [int(c) for c in req[d][3]]
-                rows = torch.cat(parts) if sum(len(p) for p in parts) else torch.empty((1, 5), dtype=torch.float64, device="cuda")
+                rows = torch.cat(parts) if sum(len(p) for p in parts) else torch.empty((1, 6), dtype=torch.float64, device="cuda")
                 vals[d] = rows.contiguous()
         settle()
         for k in range(W):
@@ -163,28 +165,40 @@ def _lockstep_fn(rank, world, dist, sizes, z_meas, record_cap):
     out = []
     for k, f in enumerate(filt):
         Xo, wo, _ = f.b.ctx.get_particles()
-        out.append({"ok": done[k], "idx": f.b.ctx.get_indices() if done[k] else None, "X": Xo, "w": wo})
+        out.append({"ok": done[k], "idx": f.b.ctx.get_indices() if done[k] else None, "X": Xo, "w": wo,
+                    "rows_sent": f.rows_sent_total, "rows_off_rank": f.rows_sent_off_rank})
     return out
 
 
-@pytest.mark.parametrize("sizes", [(16384, 8192), (8192, 8192, 11000), (8192,) * 8])
-def test_device_driven_step_of_several_ranks_equals_one_context(sizes):
-    """The device-side combination of several ranks' chunk sums, record lists and boundary counts,
+@pytest.mark.parametrize("sizes,flat", [((16384, 8192), False), ((8192, 8192, 11000), False), ((8192,) * 8, False),
+                                        ((8192, 8192, 11000), True), ((8192,) * 8, True)])
+def test_device_driven_step_of_several_ranks_equals_one_context(sizes, flat):
+    """The device-side combination of several ranks' chunk sums, record lists and drawn-row counts,
     fed with real multi-rank data (ranks run in lockstep inside one process): bit-equal to the
-    fused single-context update."""
+    fused single-context update.  Only rows that some position draws travel: with peaked weights a
+    small fraction of the particle set; with equal weights (flat: a map without obstacles) every
+    row is drawn once and stays on its rank, up to the rows at the rank boundaries."""
     from slam_amd import _lib
     M = sum(sizes)
     X, noise, r = _inputs(M)
-    ref = _setup(_lib.F32)
+    ref = _setup(_lib.F32, flat)
     z_meas = ref.raycast(np.array([3.0, 4.5, 0.0]), want_hits=False)[0][0]
     ref.set_particles(X)
     ref.shard_sample(1.5, 0.0, 0.1, ALPHA, z_meas, noise, 99, _lib.W_LOG)   # log-weights only, as the ranks run it
     ref.normalise(_lib.W_LOG)
     idx = ref.resample(r, _lib.RESAMPLE_PARALLEL)
     Xr, wr, _ = ref.get_particles()
-    res = run_ranks(_lockstep_fn, 1, sizes, z_meas, 256, backend="nccl")[0]
+    res = run_ranks(_lockstep_fn, 1, sizes, z_meas, 256, flat, backend="nccl")[0]
     assert all(x["ok"] for x in res)
     assert np.array_equal(np.concatenate([x["idx"] for x in res]), idx)
+    sent, off_rank = sum(x["rows_sent"] for x in res), sum(x["rows_off_rank"] for x in res)
+    print("%d ranks, %d particles, %s weights: %d rows exchanged (%d between ranks), %d distinct ancestors"
+          % (len(sizes), M, "equal" if flat else "peaked", sent, off_rank, len(np.unique(idx))))
+    assert len(np.unique(idx)) <= sent <= len(np.unique(idx)) + 2 * len(sizes) * len(sizes)
+    if flat:
+        assert off_rank <= 4 * len(sizes) and sent >= 0.9 * M       # every on-map row once, on its own rank
+    else:
+        assert sent < 0.5 * M
     assert np.array_equal(np.concatenate([x["X"] for x in res]), Xr)
     assert np.array_equal(np.concatenate([x["w"] for x in res]), wr)
 

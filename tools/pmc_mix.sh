@@ -1,13 +1,14 @@
 #!/bin/bash
 # rocprofv3 counter passes over tools/prof_step.py (three steps of the benchmark workload): the vector-instruction
 # mix by type, busy / wait cycles, LDS and memory traffic.  One pass per run; summaries via tools/pmc_summary.py.
-# usage: tools/pmc_mix.sh <tag>      -> gpurun_out/<tag>/pmc_*/
+# usage: tools/pmc_mix.sh <tag> [script.py]     -> gpurun_out/<tag>/pmc_*/   (default script: tools/prof_step.py)
 out=gpurun_out/${1:-mix}
+script=${2:-tools/prof_step.py}
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 run() {   # name counters...
   local name=$1; shift
-  timeout -s KILL 150 rocprofv3 --pmc "$@" --output-format csv -d $out/pmc_$name -o p -- python tools/prof_step.py > $out/pmc_$name.log 2>&1 || { echo "pass $name failed"; tail -5 $out/pmc_$name.log; exit 1; }
+  timeout -s KILL 150 rocprofv3 --pmc "$@" --output-format csv -d $out/pmc_$name -o p -- python $script > $out/pmc_$name.log 2>&1 || { echo "pass $name failed"; tail -5 $out/pmc_$name.log; exit 1; }
 }
 run f64 SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT
 run f32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM
