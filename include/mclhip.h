@@ -268,6 +268,17 @@ int mclhip_shard_pack(mclhip_ctx* ctx, const int64_t* lo, const int64_t* hi, int
 int mclhip_shard_unpack_resample(mclhip_ctx* ctx, const void* rows, int64_t L, double r, int64_t row0_global,
                                  int64_t* idx_out);
 
+/* The same exchange with only the rows that some position draws (mc_localization.py:253-259
+ * and fast_slam1.py:421-431 read X[i] / Y[i] only for the drawn i): after mclhip_shard_finalize,
+ * counts_out[d] (host, [world]) = rows this rank sends to rank d; mclhip_shard_pack_drawn writes
+ * them destination after destination as rows of six doubles (x, y, theta, w, running sum, global
+ * index as int64 bits); mclhip_shard_unpack_drawn resamples the local positions from the L rows
+ * received from all ranks (ascending global index) and remembers which received row every
+ * position took (for mclhip_fs_shard_unpack). */
+int mclhip_shard_plan_drawn(mclhip_ctx* ctx, const int64_t* firsts, int world, int rank, double r, int64_t* counts_out);
+int mclhip_shard_pack_drawn(mclhip_ctx* ctx, int world, void* rows);
+int mclhip_shard_unpack_drawn(mclhip_ctx* ctx, const void* rows, int64_t L, double r, int64_t* idx_out);
+
 /* Device-driven variant of the multi-GPU step.  No counterpart in the reference
  * (it is single-process).  Same arithmetic as the mclhip_shard_* calls above, but
  * every call only enqueues on the context's stream and exchanges data through
@@ -402,9 +413,11 @@ int mclhip_fs_max_features(mclhip_ctx* ctx, int32_t* max_out);
 int mclhip_fs_set_row_slots(mclhip_ctx* ctx, int slots);
 /* Feature rows of the local particles [lo[k], hi[k]) -> rows (host or device memory). */
 int mclhip_fs_shard_pack(mclhip_ctx* ctx, const int64_t* lo, const int64_t* hi, int nslices, void* rows);
-/* After mclhip_shard_unpack_resample: every local particle takes the feature slots
- * of its ancestor from the L received rows (global index of row 0 = row0_global). */
-int mclhip_fs_shard_unpack(mclhip_ctx* ctx, const void* rows, int64_t L, int64_t row0_global);
+/* Feature rows of the particles mclhip_shard_pack_drawn selected, in the same order. */
+int mclhip_fs_shard_pack_drawn(mclhip_ctx* ctx, void* rows);
+/* After mclhip_shard_unpack_drawn: every local particle takes the feature slots of its
+ * ancestor from the L received rows (the row that call chose for it). */
+int mclhip_fs_shard_unpack(mclhip_ctx* ctx, const void* rows, int64_t L);
 
 /* Measurement ------------------------------------------------------------ */
 

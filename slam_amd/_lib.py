@@ -105,7 +105,11 @@ PROTOTYPES = {
     "mclhip_fs_max_features": (C.c_int, [_ctx_p, C.POINTER(C.c_int32)]),
     "mclhip_fs_set_row_slots": (C.c_int, [_ctx_p, C.c_int]),
     "mclhip_fs_shard_pack": (C.c_int, [_ctx_p, _i64_p, _i64_p, C.c_int, C.c_void_p]),
-    "mclhip_fs_shard_unpack": (C.c_int, [_ctx_p, C.c_void_p, C.c_int64, C.c_int64]),
+    "mclhip_fs_shard_pack_drawn": (C.c_int, [_ctx_p, C.c_void_p]),
+    "mclhip_fs_shard_unpack": (C.c_int, [_ctx_p, C.c_void_p, C.c_int64]),
+    "mclhip_shard_plan_drawn": (C.c_int, [_ctx_p, _i64_p, C.c_int, C.c_int, C.c_double, _i64_p]),
+    "mclhip_shard_pack_drawn": (C.c_int, [_ctx_p, C.c_int, C.c_void_p]),
+    "mclhip_shard_unpack_drawn": (C.c_int, [_ctx_p, C.c_void_p, C.c_int64, C.c_double, _i64_p]),
     "mclhip_timing_enable": (C.c_int, [_ctx_p, C.c_int]),
     "mclhip_timing_get": (C.c_int, [_ctx_p, C.c_int, _i64_p, _dbl_p]),
 }
@@ -574,9 +578,27 @@ class Context:
         self._ck(self.lib.mclhip_fs_shard_pack(self.h, _p(lo, _i64_p), _p(hi, _i64_p), len(lo), C.c_void_p(rows_ptr)),
                  "mclhip_fs_shard_pack")
 
-    def fs_shard_unpack(self, rows_ptr, L, row0_global):
-        self._ck(self.lib.mclhip_fs_shard_unpack(self.h, C.c_void_p(rows_ptr), int(L), int(row0_global)),
-                 "mclhip_fs_shard_unpack")
+    def fs_shard_pack_drawn(self, rows_ptr):
+        self._ck(self.lib.mclhip_fs_shard_pack_drawn(self.h, C.c_void_p(rows_ptr)), "mclhip_fs_shard_pack_drawn")
+
+    def fs_shard_unpack(self, rows_ptr, L):
+        self._ck(self.lib.mclhip_fs_shard_unpack(self.h, C.c_void_p(rows_ptr), int(L)), "mclhip_fs_shard_unpack")
+
+    def shard_plan_drawn(self, firsts, rank, r):
+        f = np.ascontiguousarray(firsts, np.int64)
+        out = np.zeros(len(f) - 1, np.int64)
+        self._ck(self.lib.mclhip_shard_plan_drawn(self.h, _p(f, _i64_p), len(f) - 1, int(rank), float(r), _p(out, _i64_p)),
+                 "mclhip_shard_plan_drawn")
+        return out
+
+    def shard_pack_drawn(self, world, rows_ptr):
+        self._ck(self.lib.mclhip_shard_pack_drawn(self.h, int(world), C.c_void_p(rows_ptr)), "mclhip_shard_pack_drawn")
+
+    def shard_unpack_drawn(self, rows_ptr, L, r, want_idx=False):
+        idx = np.empty(self.num_particles(), np.int64) if want_idx else None
+        self._ck(self.lib.mclhip_shard_unpack_drawn(self.h, C.c_void_p(rows_ptr), int(L), float(r), _p(idx, _i64_p)),
+                 "mclhip_shard_unpack_drawn")
+        return idx
 
     def fs_feature_counts(self):
         """Features per particle and the next feature id of every particle (no feature data is copied)."""

@@ -346,7 +346,7 @@ void mclhip_destroy(mclhip_ctx* c) {
                   c->sx, c->sy, c->sth, c->sw, c->chunk_sums, c->scal, c->cdf_approx, c->cdf_exact, c->kscan,
                   c->fscan, c->blk_a, c->blk_b, c->irr, c->bases, c->idx, c->noise, c->counters, c->range_noise, c->inj_rows, c->stamps,
                   c->inj_poses, c->g_records, c->g_bases, c->gl_mask, c->gl_x, c->gl_y, c->gl_th, c->gl_cell, c->gl_pk, c->gl_pk_pred, c->gl_K, c->gl_part, c->gl_cls, c->gl_cls_first, c->gl_member, c->gl_mbeta, c->gl_zt, c->gl_el, c->gl_zm,
-                  c->rows_send, c->rows_recv, c->small_d, c->small_i};
+                  c->rows_send, c->rows_recv, c->small_d, c->small_i, c->sel};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (c->zpin) (void)hipHostFree(c->zpin);
@@ -1111,7 +1111,7 @@ int mclhip_dshard_pack(mclhip_ctx* c, int world, void* d_rows) {
   MCL_TRY(need(c, false, false, true));
   if (!d_rows || world < 1 || world > 64) return fail(c, MCLHIP_E_ARG, "d_rows NULL or world outside 1..64");
   span_begin(c, c->spans, 2);
-  MCL_TRY(launch_pack_drawn(c, world, (double*)d_rows));
+  MCL_TRY(launch_pack_drawn(c, world, (double*)d_rows, nullptr));
   span_end(c, c->spans);
   return MCLHIP_OK;
 }
@@ -1121,7 +1121,7 @@ int mclhip_dshard_unpack_resample(mclhip_ctx* c, const void* d_rows, int64_t L, 
   MCL_TRY(need(c, false, false, true));
   if (!d_rows || L <= 0) return fail(c, MCLHIP_E_ARG, "d_rows NULL or empty");
   span_begin(c, c->spans, 2);
-  MCL_TRY(launch_unpack_drawn(c, (const double*)d_rows, L, r));
+  MCL_TRY(launch_unpack_drawn(c, (const double*)d_rows, L, r, false));
   span_end(c, c->spans);
   return MCLHIP_OK;
 }
@@ -1147,7 +1147,7 @@ int mclhip_shard_pack(mclhip_ctx* c, const int64_t* lo, const int64_t* hi, int n
   if (total == 0) return MCLHIP_OK;
   if (!rows) return fail(c, MCLHIP_E_ARG, "rows is NULL");
   if (total > c->rows_send_cap) {
-    MCL_TRY(dev_alloc(c, &c->rows_send, (size_t)(total + total / 4) * 5 * sizeof(double)));
+    MCL_TRY(dev_alloc(c, &c->rows_send, (size_t)(total + total / 4) * 6 * sizeof(double)));   // capacity in rows of up to six doubles
     c->rows_send_cap = total + total / 4;
   }
   span_begin(c, c->spans, 2);
@@ -1170,7 +1170,7 @@ int mclhip_shard_unpack_resample(mclhip_ctx* c, const void* rows, int64_t L, dou
   if (!rows || L <= 0) return fail(c, MCLHIP_E_ARG, "rows NULL or empty");
   if (c->m_total <= 0) return fail(c, MCLHIP_E_STATE, "call mclhip_shard_set first");
   if (L > c->rows_recv_cap) {
-    MCL_TRY(dev_alloc(c, &c->rows_recv, (size_t)(L + L / 4) * 5 * sizeof(double)));
+    MCL_TRY(dev_alloc(c, &c->rows_recv, (size_t)(L + L / 4) * 6 * sizeof(double)));
     c->rows_recv_cap = L + L / 4;
   }
   MCL_HIP(c, hipMemcpyAsync(c->rows_recv, rows, (size_t)L * 5 * sizeof(double), hipMemcpyDefault, c->stream));
@@ -1179,6 +1179,62 @@ int mclhip_shard_unpack_resample(mclhip_ctx* c, const void* rows, int64_t L, dou
   span_end(c, c->spans);
   MCL_HIP(c, hipStreamSynchronize(c->stream));
   span_collect(c, c->spans);
+  if (idx_out) MCL_HIP(c, hipMemcpy(idx_out, c->idx, c->M * sizeof(int64_t), hipMemcpyDeviceToHost));
+  return MCLHIP_OK;
+}
+
+// ---- the drawn-row exchange for the host-combined path (rows may be host or device memory) ----
+
+int mclhip_shard_plan_drawn(mclhip_ctx* c, const int64_t* firsts, int world, int rank, double r, int64_t* counts_out) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, false, false, true));
+  if (!counts_out) return fail(c, MCLHIP_E_ARG, "counts_out is NULL");
+  if (c->m_total <= 0) return fail(c, MCLHIP_E_STATE, "call mclhip_shard_set first");
+  ShardLayout lay;
+  MCL_TRY(make_layout(c, lay, firsts, world, rank));
+  if (!c->small_i) MCL_TRY(dev_alloc(c, &c->small_i, 1024 * sizeof(int64_t)));
+  int64_t* d_counts = c->small_i + 8 + 4 * 64;
+  MCL_TRY(launch_plan_drawn(c, lay, r, d_counts, nullptr));
+  MCL_HIP(c, hipMemcpyAsync(counts_out, d_counts, world * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+  MCL_HIP(c, hipStreamSynchronize(c->stream));
+  c->drawn_total = 0;
+  for (int d = 0; d < world; ++d) c->drawn_total += counts_out[d];
+  return MCLHIP_OK;
+}
+
+int mclhip_shard_pack_drawn(mclhip_ctx* c, int world, void* rows) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, false, false, true));
+  if (world < 1 || world > 64) return fail(c, MCLHIP_E_ARG, "world outside 1..64");
+  const int64_t total = c->drawn_total;
+  if (total == 0) return MCLHIP_OK;
+  if (!rows) return fail(c, MCLHIP_E_ARG, "rows is NULL");
+  if (total > c->rows_send_cap) {
+    MCL_TRY(dev_alloc(c, &c->rows_send, (size_t)(total + total / 4) * 6 * sizeof(double)));
+    c->rows_send_cap = total + total / 4;
+  }
+  if (total > c->sel_cap) {
+    MCL_TRY(dev_alloc(c, &c->sel, (size_t)(total + total / 4) * sizeof(int64_t)));
+    c->sel_cap = total + total / 4;
+  }
+  MCL_TRY(launch_pack_drawn(c, world, (double*)c->rows_send, c->sel));
+  MCL_HIP(c, hipMemcpyAsync(rows, c->rows_send, (size_t)total * 6 * sizeof(double), hipMemcpyDefault, c->stream));
+  MCL_HIP(c, hipStreamSynchronize(c->stream));
+  return MCLHIP_OK;
+}
+
+int mclhip_shard_unpack_drawn(mclhip_ctx* c, const void* rows, int64_t L, double r, int64_t* idx_out) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, false, false, true));
+  if (!rows || L <= 0) return fail(c, MCLHIP_E_ARG, "rows NULL or empty");
+  if (c->m_total <= 0) return fail(c, MCLHIP_E_STATE, "call mclhip_shard_set first");
+  if (L > c->rows_recv_cap) {
+    MCL_TRY(dev_alloc(c, &c->rows_recv, (size_t)(L + L / 4) * 6 * sizeof(double)));
+    c->rows_recv_cap = L + L / 4;
+  }
+  MCL_HIP(c, hipMemcpyAsync(c->rows_recv, rows, (size_t)L * 6 * sizeof(double), hipMemcpyDefault, c->stream));
+  MCL_TRY(launch_unpack_drawn(c, (const double*)c->rows_recv, L, r, true));
+  MCL_HIP(c, hipStreamSynchronize(c->stream));
   if (idx_out) MCL_HIP(c, hipMemcpy(idx_out, c->idx, c->M * sizeof(int64_t), hipMemcpyDeviceToHost));
   return MCLHIP_OK;
 }

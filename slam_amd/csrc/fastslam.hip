@@ -582,12 +582,36 @@ __global__ void fs_pack_rows_kernel(int64_t lo, int64_t n, int F, int R, const i
   dst[8] = (unsigned long long)(long long)FLD_I(f, F_INT, 1);
 }
 
+// the same for a list of local particles: row j of the output holds particle sel[j]
+__global__ void fs_pack_sel_kernel(const int64_t* __restrict__ sel, int64_t n, int F, int R, const int32_t* __restrict__ nfeat,
+                                   const int32_t* __restrict__ newid, const double* __restrict__ feat,
+                                   unsigned long long* __restrict__ out, int32_t* __restrict__ overflow) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int64_t p = sel[j];
+  unsigned long long* row = out + j * (2 + (int64_t)9 * R);
+  const int y = blockIdx.y;
+  if (y == 0) {
+    row[0] = (unsigned long long)(long long)nfeat[p]; row[1] = (unsigned long long)(long long)newid[p];
+    if (nfeat[p] > R) atomicMax(overflow, 2);
+    return;
+  }
+  const int slot = y - 1;
+  if (slot >= nfeat[p]) return;
+  unsigned long long* dst = row + 2 + (int64_t)9 * slot;
+  const double* f = feat + tile_word(p, F, slot, F_WORDS);
+#pragma unroll
+  for (int w = 0; w < 7; ++w) dst[w] = (unsigned long long)__double_as_longlong(FLD(f, w));
+  dst[7] = (unsigned long long)(long long)FLD_I(f, F_INT, 0);
+  dst[8] = (unsigned long long)(long long)FLD_I(f, F_INT, 1);
+}
+
 __global__ void fs_unpack_rows_kernel(const int64_t* __restrict__ idx, int64_t row0_global, int64_t L, int64_t M, int F, int R,
                                       const unsigned long long* __restrict__ rows, int32_t* __restrict__ nfeat,
                                       int32_t* __restrict__ newid, double* __restrict__ feat) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= M) return;
-  int64_t rr = idx[p] - row0_global;
+  int64_t rr = idx[p] - row0_global;   // row0_global == 0 with idx = the received-row positions themselves
   rr = rr < 0 ? 0 : (rr > L - 1 ? L - 1 : rr);
   const unsigned long long* row = rows + rr * (2 + (int64_t)9 * R);
   const int n = min((int)(long long)row[0], R);
@@ -972,7 +996,33 @@ int mclhip_fs_shard_pack(mclhip_ctx* c, const int64_t* lo, const int64_t* hi, in
   return MCLHIP_OK;
 }
 
-int mclhip_fs_shard_unpack(mclhip_ctx* c, const void* rows, int64_t L, int64_t row0_global) {
+int mclhip_fs_shard_pack_drawn(mclhip_ctx* c, void* rows) {
+  if (!c) return MCLHIP_E_ARG;
+  F_HIP(hipSetDevice(c->device));
+  if (!c->fs) return fail(c, MCLHIP_E_STATE, "call mclhip_fs_init first");
+  FsState* s = (FsState*)c->fs;
+  const int64_t words = 2 + (int64_t)9 * s->row_slots;
+  const int64_t total = c->drawn_total;
+  if (total == 0) return MCLHIP_OK;
+  if (!rows) return fail(c, MCLHIP_E_ARG, "rows is NULL");
+  if (!c->sel || c->sel_cap < total) return fail(c, MCLHIP_E_STATE, "call mclhip_shard_pack_drawn first (it selects the rows)");
+  F_TRY(fs_stage(c, s, total * words));
+  hipLaunchKernelGGL(fs_pack_sel_kernel, dim3((unsigned)((total + 63) / 64), s->row_slots + 1), dim3(64), 0, c->stream,
+                     (const int64_t*)c->sel, total, s->F, s->row_slots, s->nfeat[s->cur], s->newid[s->cur],
+                     (const double*)s->feat[s->cur], s->stage, s->overflow);
+  F_HIP(hipGetLastError());
+  F_HIP(hipMemcpyAsync(rows, s->stage, (size_t)total * words * 8, hipMemcpyDefault, c->stream));
+  int32_t ov = 0;
+  F_HIP(hipMemcpyAsync(&ov, s->overflow, sizeof(ov), hipMemcpyDeviceToHost, c->stream));
+  F_HIP(hipStreamSynchronize(c->stream));
+  if (ov >= 2) {
+    F_HIP(hipMemset(s->overflow, 0, sizeof(int32_t)));
+    return fail(c, MCLHIP_E_LIMIT, "a particle holds more features than an exchange row has slots (mclhip_fs_set_row_slots)");
+  }
+  return MCLHIP_OK;
+}
+
+int mclhip_fs_shard_unpack(mclhip_ctx* c, const void* rows, int64_t L) {
   if (!c) return MCLHIP_E_ARG;
   F_HIP(hipSetDevice(c->device));
   if (!c->fs) return fail(c, MCLHIP_E_STATE, "call mclhip_fs_init first");
@@ -982,8 +1032,10 @@ int mclhip_fs_shard_unpack(mclhip_ctx* c, const void* rows, int64_t L, int64_t r
   F_TRY(fs_stage(c, s, L * words));
   F_HIP(hipMemcpyAsync(s->stage, rows, (size_t)L * words * 8, hipMemcpyDefault, c->stream));
   const int b = 1 - s->cur;
-  hipLaunchKernelGGL(fs_unpack_rows_kernel, dim3((unsigned)((s->M + 63) / 64), s->row_slots + 1), dim3(64), 0, c->stream, c->idx,
-                     row0_global, L, s->M, s->F, s->row_slots, (const unsigned long long*)s->stage, s->nfeat[b], s->newid[b], s->feat[b]);
+  // the received row every local position took was left in c->kscan by mclhip_shard_unpack_drawn
+  hipLaunchKernelGGL(fs_unpack_rows_kernel, dim3((unsigned)((s->M + 63) / 64), s->row_slots + 1), dim3(64), 0, c->stream,
+                     reinterpret_cast<const int64_t*>(c->kscan), (int64_t)0, L, s->M, s->F, s->row_slots,
+                     (const unsigned long long*)s->stage, s->nfeat[b], s->newid[b], s->feat[b]);
   F_HIP(hipGetLastError());
   F_TRY(fs_count_features(c, s, s->nfeat[b]));
   F_HIP(hipStreamSynchronize(c->stream));

@@ -1046,7 +1046,7 @@ __global__ void plan_slices_kernel(const int64_t* __restrict__ G, const unsigned
   if (d == 0) {
     int64_t off = 0;
     for (int k = 0; k < lay.world; ++k) { slices[4 * k + 3] = off; off += s_cnt[k]; }
-    counts[lay.world] = (int64_t)meta[3];
+    counts[lay.world] = meta ? (int64_t)meta[3] : 0;
   }
 }
 
@@ -1057,7 +1057,8 @@ __global__ __launch_bounds__(256) void pack_drawn_kernel(const T* __restrict__ x
                                                          const double* __restrict__ w, const double* __restrict__ cdf,
                                                          const int64_t* __restrict__ G, const unsigned int* __restrict__ S,
                                                          int64_t n, int64_t first_index, int world,
-                                                         const int64_t* __restrict__ slices, double* __restrict__ dst) {
+                                                         const int64_t* __restrict__ slices, double* __restrict__ dst,
+                                                         int64_t* __restrict__ sel) {
   __shared__ int64_t s_sl[4 * 64];
   for (int k = threadIdx.x; k < 4 * world; k += blockDim.x) s_sl[k] = slices[k];
   __syncthreads();
@@ -1076,6 +1077,7 @@ __global__ __launch_bounds__(256) void pack_drawn_kernel(const T* __restrict__ x
     row[3] = w[j];
     row[4] = cdf[j];
     row[5] = __longlong_as_double((long long)(first_index + j));
+    if (sel) sel[pos] = j;                                   // which local row stands at this place of the send buffer
   }
 }
 
@@ -1085,7 +1087,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void unpack_drawn_kernel(const double* __restrict__ rows, int64_t L, int64_t first_index,
                                                            int64_t m_total, int64_t n, double r, T* __restrict__ x2,
                                                            T* __restrict__ y2, T* __restrict__ th2, double* __restrict__ w2,
-                                                           int64_t* __restrict__ idx) {
+                                                           int64_t* __restrict__ idx, int64_t* __restrict__ pos_out) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const double U = position_u(first_index + j, m_total, r);
@@ -1096,6 +1098,7 @@ __global__ __launch_bounds__(256) void unpack_drawn_kernel(const double* __restr
   }
   if (lo > L - 1) lo = L - 1;
   const double* s = rows + lo * 6;
+  if (pos_out) pos_out[j] = lo;                              // which received row this position took
   idx[j] = (int64_t)__double_as_longlong(s[5]);
   x2[j] = (T)s[0];
   y2[j] = (T)s[1];
@@ -1112,13 +1115,21 @@ int launch_dshard_scan(mclhip_ctx* c, const double* d_all_chunks, const ShardLay
   return MCLHIP_OK;
 }
 
+int launch_plan_drawn(mclhip_ctx* c, const ShardLayout& lay, double r, int64_t* d_counts, const unsigned long long* meta);
+
 int launch_dshard_finalize(mclhip_ctx* c, const void* d_all_rec, const ShardLayout& lay, int cap, double r,
                            int64_t* d_counts) {
   unsigned long long* meta = reinterpret_cast<unsigned long long*>(c->small_i);   // [4] of the 1024-entry staging
   hipLaunchKernelGGL(merge_records_kernel, dim3(1), dim3(256), 0, c->stream, (const unsigned long long*)d_all_rec,
                      lay.world, lay.rank, cap, (IrrRecord*)c->g_records, meta);
   MCL_TRY_W(launch_shard_finalize(c, c->g_records, 0, c->g_bases, 0, 0, meta));
-  // which local rows are drawn at all, and by the positions of which rank: only those travel
+  return launch_plan_drawn(c, lay, r, d_counts, meta);
+}
+
+// which local rows are drawn at all, and by the positions of which rank: only those travel.  Needs the exact running
+// sums in c->cdf_exact; leaves the draw ends in c->kscan, the scan of the drawn flags in c->fscan, the slices behind
+// c->small_i + 8 and the row counts per destination (+ the overflow word) in d_counts.
+int launch_plan_drawn(mclhip_ctx* c, const ShardLayout& lay, double r, int64_t* d_counts, const unsigned long long* meta) {
   const int64_t n = c->M;
   const unsigned g = (unsigned)((n + 255) / 256);
   const int ntile = (int)((n + kScanTile - 1) / kScanTile);
@@ -1135,13 +1146,13 @@ int launch_dshard_finalize(mclhip_ctx* c, const void* d_all_rec, const ShardLayo
                      su, n, (const unsigned int*)c->blk_a);
   int64_t* slices = c->small_i + 8;                            // [4 * world] behind the merge's four words
   hipLaunchKernelGGL(plan_slices_kernel, dim3(1), dim3(64), 0, c->stream, (const int64_t*)G, (const unsigned int*)S, n, lay,
-                     (const unsigned long long*)meta, slices, d_counts);
+                     meta, slices, d_counts);
   MCL_HIP(c, hipGetLastError());
   return MCLHIP_OK;
 }
 
 // the drawn rows of every destination, one after the other, into d_dst (six doubles per row)
-int launch_pack_drawn(mclhip_ctx* c, int world, double* d_dst) {
+int launch_pack_drawn(mclhip_ctx* c, int world, double* d_dst, int64_t* d_sel) {
   const int64_t n = c->M;
   const int a = c->cur;
   const unsigned g = (unsigned)((n + 255) / 256);
@@ -1150,25 +1161,27 @@ int launch_pack_drawn(mclhip_ctx* c, int world, double* d_dst) {
   if (c->dtype == MCLHIP_F32)
     hipLaunchKernelGGL(pack_drawn_kernel<float>, dim3(g), dim3(256), 0, c->stream, (const float*)c->px[a], (const float*)c->py[a],
                        (const float*)c->pth[a], (const double*)c->w[a], (const double*)c->cdf_exact, G, (const unsigned int*)c->fscan,
-                       n, c->first_index, world, slices, d_dst);
+                       n, c->first_index, world, slices, d_dst, d_sel);
   else
     hipLaunchKernelGGL(pack_drawn_kernel<double>, dim3(g), dim3(256), 0, c->stream, (const double*)c->px[a], (const double*)c->py[a],
                        (const double*)c->pth[a], (const double*)c->w[a], (const double*)c->cdf_exact, G, (const unsigned int*)c->fscan,
-                       n, c->first_index, world, slices, d_dst);
+                       n, c->first_index, world, slices, d_dst, d_sel);
   MCL_HIP(c, hipGetLastError());
   return MCLHIP_OK;
 }
 
-int launch_unpack_drawn(mclhip_ctx* c, const double* d_rows, int64_t L, double r) {
+// keep_pos: the received row every position took is left in c->kscan (as int64) for what travels beside the poses
+int launch_unpack_drawn(mclhip_ctx* c, const double* d_rows, int64_t L, double r, bool keep_pos) {
+  int64_t* pos = keep_pos ? reinterpret_cast<int64_t*>(c->kscan) : nullptr;
   const int64_t n = c->M;
   const int b = 1 - c->cur;
   const unsigned g = (unsigned)((n + 255) / 256);
   if (c->dtype == MCLHIP_F32)
     hipLaunchKernelGGL(unpack_drawn_kernel<float>, dim3(g), dim3(256), 0, c->stream, d_rows, L, c->first_index, c->m_total, n, r,
-                       (float*)c->px[b], (float*)c->py[b], (float*)c->pth[b], c->w[b], c->idx);
+                       (float*)c->px[b], (float*)c->py[b], (float*)c->pth[b], c->w[b], c->idx, pos);
   else
     hipLaunchKernelGGL(unpack_drawn_kernel<double>, dim3(g), dim3(256), 0, c->stream, d_rows, L, c->first_index, c->m_total, n, r,
-                       (double*)c->px[b], (double*)c->py[b], (double*)c->pth[b], c->w[b], c->idx);
+                       (double*)c->px[b], (double*)c->py[b], (double*)c->pth[b], c->w[b], c->idx, pos);
   MCL_HIP(c, hipGetLastError());
   c->cur = b;
   return MCLHIP_OK;

@@ -430,26 +430,27 @@ class ShardedFastSLAM:
         lasts = [np.frombuffer(x, np.float64)[0] for x in co.allgather_bytes(np.float64(ctx.fs_shard_last_sum()).tobytes())]
         self.total = max(1e-8, float(lasts[-1]))                 # :415
         self._exact_running_sums(self.total, all_chunks)         # w /= sum_w (:418) and c_i (:421-428)
-        M = self.m_total
-        m_edge = []
-        for d in range(world):
-            m_edge += [self.firsts[d], self.firsts[d + 1] - 1]
-        U = np.array([r + (m / M) for m in m_edge], np.float64)
-        gidx = np.minimum(co.allreduce_sum_i64(ctx.shard_count_below(U)), M - 1)   # the i < M-1 guard (:426)
-        lo, hi, send_counts, recv_counts, glo = self._plan(gidx)
-        n_send, L = int(sum(send_counts)), int(sum(recv_counts))
+        # only the particles that some position draws travel (fast_slam1.py:421-431 reads Y[i] only for the drawn i;
+        # with hundreds of landmarks the weights are peaked and a handful of ancestors feeds the whole next set)
+        mine = ctx.shard_plan_drawn(self.firsts, rank, r)
+        counts = np.stack([np.frombuffer(x, np.int64) for x in co.allgather_bytes(mine.tobytes())])    # [source, destination]
+        send_counts = [int(c) for c in counts[rank]]
+        recv_counts = [int(c) for c in counts[:, rank]]
+        n_send, L = sum(send_counts), sum(recv_counts)
+        self.rows_sent_total = getattr(self, "rows_sent_total", 0) + n_send
+        self.rows_sent_off_rank = getattr(self, "rows_sent_off_rank", 0) + n_send - send_counts[rank]
         # feature rows as long as the longest feature list of any rank, not as the capacity
         most = max(int(np.frombuffer(x, np.int64)[0]) for x in co.allgather_bytes(np.int64(ctx.fs_max_features()).tobytes()))
         ctx.fs_set_row_slots(max(1, min(most, self.capacity)))
         self.words = ctx.fs_row_words()
-        send = co.rows(n_send)
+        send = co.rows(n_send, 6)
         fsend = co.rows(n_send, self.words, co.torch.int64)
         if n_send:
-            ctx.shard_pack(lo, hi, send.data_ptr())
-            ctx.fs_shard_pack(lo, hi, fsend.data_ptr())
+            ctx.shard_pack_drawn(world, send.data_ptr())
+            ctx.fs_shard_pack_drawn(fsend.data_ptr())
         recv = co.all_to_all_rows(send, send_counts, recv_counts)
         frecv = co.all_to_all_rows(fsend, send_counts, recv_counts)
-        self.last_idx = ctx.shard_unpack_resample(recv.data_ptr(), L, r, int(glo[rank]), True)
-        ctx.fs_shard_unpack(frecv.data_ptr(), L, int(glo[rank]))
+        self.last_idx = ctx.shard_unpack_drawn(recv.data_ptr(), L, r, True)
+        ctx.fs_shard_unpack(frecv.data_ptr(), L)
         if not want_idx:
             self.last_idx = None
