@@ -146,8 +146,12 @@ __device__ __attribute__((noinline)) double slow_log(double v) { return log(v); 
 #ifndef MCL_FAST_WAVES
 #define MCL_FAST_WAVES 7
 #endif
+// Blocks of the particle-filter launch (each wave then loops over particles).  Seven blocks of four waves fit a
+// compute unit, 1792 the chip; the launch wants several rounds of that, so that blocks which draw expensive particles
+// do not leave the chip idle at the end, but not so many that the beam tables are staged too often.  Measured at
+// 2^20 x 180 (ms): 2048 blocks 1.84, 4096 1.51, 8192 1.40, 16384 1.38, 32768 1.40, 65536 1.47, 262144 1.97.
 #ifndef MCL_MAX_BLOCKS
-#define MCL_MAX_BLOCKS (256 * 8 * 4)
+#define MCL_MAX_BLOCKS 16384
 #endif
 // WPB: wavefronts per block.  Four for the particle filter; the histogram filter's table (all headings x
 // beams) makes the per-wave LDS array large, and more waves behind one copy of the block-wide tables is
@@ -736,7 +740,7 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
   const size_t lds = ray_lds_bytes(P.B, P.G, P.NB, stage || product);
   if (lds > 160 * 1024) return fail(c, MCLHIP_E_LIMIT, "beam table does not fit the kernel's LDS budget");
   int64_t blocks = (n + kWavesPerBlock - 1) / kWavesPerBlock;
-  const int64_t max_blocks = MCL_MAX_BLOCKS;   // 8192 blocks of four waves; each wave loops over particles
+  const int64_t max_blocks = MCL_MAX_BLOCKS;
   if (blocks > max_blocks) blocks = max_blocks;
   dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
   // large beam tables need more dynamic LDS than a kernel gets by default
