@@ -14,7 +14,7 @@ therefore: (vector wave-instructions per launch, each priced with its measured i
 It also reports the hardware's own figure, SQ_ACTIVE_INST_VALU (in quad-cycles), which the priced sum should
 reproduce.
 
-    python tools/valu_roofline.py <pmc_summary.json> <issue_cost.json> <kernel.s> <kernel-name-substring> <out.json>
+    python tools/valu_roofline.py <pmc_summary.json> <issue_cost.json> <kernel.s> <symbol-substring> <out.json> [<name-in-counters>]
 """
 import json
 import re
@@ -96,11 +96,12 @@ def static_mix(asm_path, kernel_sub, table):
 
 def main():
     pmc, cost, asm, ksub, out = sys.argv[1:6]
+    pmc_name = sys.argv[6] if len(sys.argv) > 6 else "raycast_kernel<float, false, false, false"
     table = {k: v["cycles"] for k, v in json.load(open(cost))["cycles_per_wave64_instruction_per_simd"].items()}
     kname, mix = static_mix(asm, ksub, table)
     ctr = None
     for name, c in json.load(open(pmc)).items():
-        if "raycast_kernel<float, false, false, false" in name or ksub in name:
+        if pmc_name in name:
             ctr = {k: v["per_launch_mean"] for k, v in c.items()}
             pmc_kernel = name
             break
