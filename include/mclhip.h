@@ -376,7 +376,10 @@ int mclhip_fs_set_model(mclhip_ctx* ctx, double std_r, double std_phi, double r_
  * generator.  normals [M][2 * #valid]: the standard normals of the measurements
  * in consumption order, NULL = device generator keyed by `seed`.
  * r = np.random.rand() * 1/M (:423).  idx_out [M] nullable: ancestor indices.
- * Returns MCLHIP_E_LIMIT when a particle needs more feature slots than capacity. */
+ * Returns MCLHIP_E_LIMIT when a particle needs more feature slots than capacity.
+ * Order on the device: the weights of all particles first (they need the association
+ * and the decay bookkeeping, not the updated means), the walk of :421-431, and then the
+ * updates of :318-404 for the drawn ancestors only, whose slots their descendants copy. */
 int mclhip_fs_step(mclhip_ctx* ctx, double v, double omega, double dt, const double alpha[6], const double* truth_r,
                    const double* truth_phi, const uint8_t* truth_valid, int L, const int16_t* ints,
                    const double* normals, uint64_t seed, double r, int64_t* idx_out);
@@ -396,7 +399,11 @@ int mclhip_fs_get_state(mclhip_ctx* ctx, double* pose, double* w, int32_t* nfeat
  * mclhip_fs_row_words() 64-bit words. */
 
 /* The per-particle part of fast_slam1.py:246-404 on this rank's particles (device
- * generators are keyed by the global particle index); leaves the raw weights. */
+ * generators are keyed by the global particle index): pose, measurements,
+ * association and the raw weights of all of them.  The EKF updates, births and the
+ * feature decay (:318-404) are applied to a particle when its row is packed
+ * (mclhip_fs_shard_pack, mclhip_fs_shard_pack_drawn) or by mclhip_fs_get_state: a
+ * particle that no position draws is replaced by the resampling and is never updated. */
 int mclhip_fs_shard_kernel(mclhip_ctx* ctx, double v, double omega, double dt, const double alpha[6],
                            const double* truth_r, const double* truth_phi, const uint8_t* truth_valid, int L,
                            const int16_t* ints, const double* normals, uint64_t seed);
@@ -411,7 +418,8 @@ int64_t mclhip_fs_row_words(mclhip_ctx* ctx);
  * the live features and not the unused capacity).  Packing a particle with more features than that fails. */
 int mclhip_fs_max_features(mclhip_ctx* ctx, int32_t* max_out);
 int mclhip_fs_set_row_slots(mclhip_ctx* ctx, int slots);
-/* Feature rows of the local particles [lo[k], hi[k]) -> rows (host or device memory). */
+/* Feature rows of the local particles [lo[k], hi[k]) -> rows (host or device memory);
+ * between mclhip_fs_shard_kernel and mclhip_fs_shard_unpack with that step's updates applied. */
 int mclhip_fs_shard_pack(mclhip_ctx* ctx, const int64_t* lo, const int64_t* hi, int nslices, void* rows);
 /* Feature rows of the particles mclhip_shard_pack_drawn selected, in the same order. */
 int mclhip_fs_shard_pack_drawn(mclhip_ctx* ctx, void* rows);

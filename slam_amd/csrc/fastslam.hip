@@ -1,10 +1,12 @@
 // FastSLAM 1.0 with unknown correspondence -- the reference's 13_fast_slam/fast_slam1.py
 // (fast_slam(), :240-433) on the GPU.
 //
-// One thread per particle, four kernels per filter step: pose sample (Table 5.3 with the twelve-integer
+// One thread per particle.  Kernels of a filter step: pose sample (Table 5.3 with the twelve-integer
 // normal sampler, :160-189); measurement draws; maximum-likelihood association of every sensed landmark
-// with a 2-sigma Mahalanobis gate (:286-315); one sweep over the features for the EKF updates (:348-375), the
-// births (:318-347) and the weight / feature-decay pass that removes from the list it iterates (:377-404).  The per-feature measurement
+// with a 2-sigma Mahalanobis gate (:286-315); a sweep over the features that forms the particle's weight the way
+// the weight / feature-decay pass does (:377-404, it removes from the list it iterates); resampling; and then,
+// only for the particles that were drawn, the sweep that applies the EKF updates (:348-375), the births (:318-347)
+// and the decay, before the slots of the drawn ancestors are copied to their descendants.  The per-feature measurement
 // prediction / Jacobian / innovation covariance of :259-282 is never stored: it is a function of the
 // feature as it stood before the step and of the sampled pose, so the association sweep and the update
 // each form it from the 48 bytes of the feature they read anyway (same expressions, same results), which
@@ -395,27 +397,35 @@ __device__ inline void ekf_update(Slot& d, const Predicted& pr, const M2& H, dou
 // ---- EKF updates (:348-375), births (:318-347) and the weight / feature-decay pass (:377-404) as ONE sweep
 // over the particle's features in list order.  What a feature needs to know -- which measurement picked it --
 // is the inverse of the association, built per thread in LDS (per live slot the first measurement that picked
-// it, per measurement the next one that picked the same feature); the sweep then reads every slot once, a step ahead of its use, and
-// writes it once, closing ranks over discarded features as it goes.  The reference removes from the list its
+// it, per measurement the next one that picked the same feature).  The reference removes from the list its
 // for-loop walks, so the feature that slides into a vacated slot is not visited by the pass (`slid`); births
 // stand behind the old features in the list and are visited last.
+//
+// The sweep runs twice per filter step.  FS_WEIGH, for every particle, forms the particle's weight and changes
+// nothing: a weight needs, per feature, whether it was picked (then the likelihood of its last picker) or else
+// its position and counter (the decay visit decides whether the NEXT feature is visited) -- 32 of a slot's 64
+// bytes, and no arithmetic of the update.  FS_APPLY, after resampling, for the particles that were drawn at least
+// once (`state[p] == 1`): reads every slot once, a step ahead of its use, applies the updates and the decay,
+// writes the slot once at its compacted position, appends the births.  A particle nobody descends from is never
+// updated: its slots are dead once the survivors' slots have been copied.
 // IT: unsigned char while fewer than 255 measurements are in range, else unsigned short.
 // Dynamic LDS: births [blocks of 64 measurements][128] u64, then the inverse [rows][128] IT, rows >= every
 // particle's feature count, then the chains [measurements][128] IT.
-template <typename IT>
-__global__ __launch_bounds__(128, FS_UPDATE_WAVES) void fs_update_kernel(const FsParams P, int rows) {
+enum { FS_WEIGH = 0, FS_APPLY = 1 };
+template <typename IT, int MODE>
+__global__ __launch_bounds__(128, FS_UPDATE_WAVES) void fs_update_kernel(const FsParams P, int rows, uint8_t* __restrict__ state) {
   extern __shared__ __align__(16) unsigned char fs_update_lds[];
   constexpr unsigned kNone = (IT)~(IT)0;
   const int tid = threadIdx.x;
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + tid;
   if (p >= P.M) return;
+  if (MODE == FS_APPLY && state[p] != 1) return;
   const int nv = P.L, nblk = (nv + 63) >> 6;
   unsigned long long* const s_birth = reinterpret_cast<unsigned long long*>(fs_update_lds);   // [nblk][128]
   IT* const s_inv = reinterpret_cast<IT*>(s_birth + (size_t)nblk * 128);                     // [rows][128]
   IT* const s_next = s_inv + (size_t)rows * 128;                                              // [nv][128]
   const double x = P.x[p], y = P.y[p], th = P.th[p];
   const int n_old = min(P.nfeat[p], rows);
-  int32_t new_id = P.new_id[p];
   for (int j = 0; j < n_old; ++j) s_inv[j * 128 + tid] = (IT)kNone;
   // the association, inverted: sixteen picks are read together, then filed -- last measurement first, so that a
   // slot ends up with its first picker and every picker points to the next one of the same feature
@@ -440,86 +450,139 @@ __global__ __launch_bounds__(128, FS_UPDATE_WAVES) void fs_update_kernel(const F
     }
     s_birth[blk * 128 + tid] = birth;
   }
-  double wgt = 1.0;
-  int n_assoc = 0;
-  int kept = 0;            // slots written so far: survivors close ranks as the pass goes
   bool slid = false;       // the previous feature was discarded, this one takes its place unvisited
-  // slot j + 1 and the measurement that picked it are on their way while slot j is worked on (two ahead: no gain)
-  struct Ahead { Slot sl; unsigned e; double zr, zp, bw; };
-  auto fetch = [&](int jj) {
-    Ahead a;
-    a.sl = Slot{1.0, 0.0, M2{1.0, 0.0, 0.0, 1.0}, 0.0, 0, 0};
-    a.e = kNone; a.zr = a.zp = a.bw = 0.0;
-    if (jj < n_old) {
-      a.sl = load_slot(FREC(jj));
-      a.e = s_inv[jj * 128 + tid];
-      if (a.e != kNone) { const double* m = MREC(a.e); a.zr = FLD(m, M_ZR); a.zp = FLD(m, M_ZPHI); a.bw = FLD(m, M_BW); }
-    }
-    return a;
-  };
-  Ahead a1 = fetch(0);
-  for (int j = 0; j < n_old; ++j) {
-    Slot cur = a1.sl;
-    const unsigned e = a1.e;
-    const double zr = a1.zr, zp = a1.zp, bw = a1.bw;
-    a1 = fetch(j + 1);
-    const bool upd = e != kNone;
-    if (upd) {
-      M2 H;
-      const Predicted pr = predict_feature(RawFeat{cur.m0, cur.m1, cur.C.a, cur.C.b, cur.C.c, cur.C.d}, x, y, th, P.qt_r, P.qt_phi, &H);
-      ekf_update(cur, pr, H, zr, zp, bw);
-      // rare: the other measurements that picked this feature, in landmark order, same prediction
-      for (unsigned u2 = s_next[e * 128 + tid]; u2 != kNone; u2 = s_next[u2 * 128 + tid]) {
-        const double* m = MREC(u2);
-        ekf_update(cur, pr, H, FLD(m, M_ZR), FLD(m, M_ZPHI), FLD(m, M_BW));
+  if constexpr (MODE == FS_WEIGH) {
+    double wgt = 1.0;
+    int n_assoc = 0;
+    // slot j + 1's position and counter, and the likelihood of the last measurement that picked it, are on their
+    // way while slot j is looked at
+    struct Ahead { double m0, m1, bw; int cnt; bool upd; };
+    auto fetch = [&](int jj) {
+      Ahead a{0.0, 0.0, 0.0, 0, false};
+      if (jj < n_old) {
+        const double* f = FREC(jj);
+        a.m0 = FLD(f, F_M0); a.m1 = FLD(f, F_M1); a.cnt = FLD_I(f, F_INT, 0);
+        unsigned e = s_inv[jj * 128 + tid];
+        if (e != kNone) {
+          for (unsigned u2 = s_next[e * 128 + tid]; u2 != kNone; u2 = s_next[u2 * 128 + tid]) e = u2;
+          a.upd = true;
+          a.bw = FLD(MREC(e), M_BW);
+        }
+      }
+      return a;
+    };
+    Ahead a1 = fetch(0);
+    for (int j = 0; j < n_old; ++j) {
+      const Ahead cur = a1;
+      a1 = fetch(j + 1);
+      if (slid) {
+        slid = false;
+      } else if (cur.upd) {
+        wgt = wgt * cur.bw;
+        ++n_assoc;
+      } else {
+        const double dx = cur.m0 - x, dy = cur.m1 - y;
+        if (dx * dx + dy * dy <= P.r_max2 && cur.cnt - 1 < 0) slid = true;   // discarded
       }
     }
-    bool keep = true, touched = upd;
-    if (slid) {
-      slid = false;
-    } else if (upd) {
-      wgt = wgt * cur.w;
-      ++n_assoc;
-    } else {
-      const double dx = cur.m0 - x, dy = cur.m1 - y;
-      cur.w = P.p0;
-      touched = true;
-      if (dx * dx + dy * dy <= P.r_max2) {
-        cur.cnt = cur.cnt - 1;
-        if (cur.cnt < 0) { keep = false; slid = true; }   // discard
+    int n_list = n_old;
+    for (int blk = 0; blk < nblk; ++blk) {
+      int births = __popcll(s_birth[blk * 128 + tid]);
+      for (; births > 0; --births) {
+        if (n_list >= P.F) { atomicMax(P.overflow, 1); continue; }
+        ++n_list;
+        if (slid) slid = false;
+        else { wgt = wgt * P.p0; ++n_assoc; }
       }
     }
-    if (keep) {
-      double* g = FREC(kept);
-      if (upd || kept != j) {
-        store_slot(g, cur);
-      } else if (touched) {                    // only the weight / counter pair changed
-        FLD(g, F_W) = cur.w;
-        FLD_I(g, F_INT, 0) = cur.cnt; FLD_I(g, F_INT, 1) = cur.id;
+    if (n_assoc == 0) wgt = P.p0;
+    P.wout[p] = wgt;
+  } else {
+    int32_t new_id = P.new_id[p];
+    int kept = 0;            // slots written so far: survivors close ranks as the pass goes
+    // slot j + 1 and the measurement that picked it are on their way while slot j is worked on (two ahead: no gain)
+    struct Ahead { Slot sl; unsigned e; double zr, zp, bw; };
+    auto fetch = [&](int jj) {
+      Ahead a;
+      a.sl = Slot{1.0, 0.0, M2{1.0, 0.0, 0.0, 1.0}, 0.0, 0, 0};
+      a.e = kNone; a.zr = a.zp = a.bw = 0.0;
+      if (jj < n_old) {
+        a.sl = load_slot(FREC(jj));
+        a.e = s_inv[jj * 128 + tid];
+        if (a.e != kNone) { const double* m = MREC(a.e); a.zr = FLD(m, M_ZR); a.zp = FLD(m, M_ZPHI); a.bw = FLD(m, M_BW); }
       }
-      ++kept;
+      return a;
+    };
+    Ahead a1 = fetch(0);
+    for (int j = 0; j < n_old; ++j) {
+      Slot cur = a1.sl;
+      const unsigned e = a1.e;
+      const double zr = a1.zr, zp = a1.zp, bw = a1.bw;
+      a1 = fetch(j + 1);
+      const bool upd = e != kNone;
+      if (upd) {
+        M2 H;
+        const Predicted pr = predict_feature(RawFeat{cur.m0, cur.m1, cur.C.a, cur.C.b, cur.C.c, cur.C.d}, x, y, th, P.qt_r, P.qt_phi, &H);
+        ekf_update(cur, pr, H, zr, zp, bw);
+        // rare: the other measurements that picked this feature, in landmark order, same prediction
+        for (unsigned u2 = s_next[e * 128 + tid]; u2 != kNone; u2 = s_next[u2 * 128 + tid]) {
+          const double* m = MREC(u2);
+          ekf_update(cur, pr, H, FLD(m, M_ZR), FLD(m, M_ZPHI), FLD(m, M_BW));
+        }
+      }
+      bool keep = true, touched = upd;
+      if (slid) {
+        slid = false;
+      } else if (!upd) {
+        const double dx = cur.m0 - x, dy = cur.m1 - y;
+        cur.w = P.p0;
+        touched = true;
+        if (dx * dx + dy * dy <= P.r_max2) {
+          cur.cnt = cur.cnt - 1;
+          if (cur.cnt < 0) { keep = false; slid = true; }   // discard
+        }
+      }
+      if (keep) {
+        double* g = FREC(kept);
+        if (upd || kept != j) {
+          store_slot(g, cur);
+        } else if (touched) {                    // only the weight / counter pair changed
+          FLD(g, F_W) = cur.w;
+          FLD_I(g, F_INT, 0) = cur.cnt; FLD_I(g, F_INT, 1) = cur.id;
+        }
+        ++kept;
+      }
     }
+    // births, in landmark order; n_list: length of the reference's list before anything is discarded
+    int n_list = n_old;
+    for (int blk = 0; blk < nblk; ++blk) {
+      unsigned long long births = s_birth[blk * 128 + tid];
+      while (births) {
+        const int u = (blk << 6) + __ffsll((long long)births) - 1;
+        births &= births - 1;
+        if (n_list >= P.F) continue;             // reported by the weighing sweep
+        const double* m = MREC(u);
+        create_feature(FREC(kept), new_id++, FLD(m, M_ZR), FLD(m, M_ZPHI), x, y, th, P.qt_r, P.qt_phi, P.p0);
+        ++n_list;
+        ++kept;
+      }
+    }
+    P.nfeat[p] = kept;
+    P.new_id[p] = new_id;
+    state[p] = 2;            // applied: a second request for this particle in the same step finds nothing to do
   }
-  // births, in landmark order; n_list: length of the reference's list before anything is discarded
-  int n_list = n_old;
-  for (int blk = 0; blk < nblk; ++blk) {
-    unsigned long long births = s_birth[blk * 128 + tid];
-    while (births) {
-      const int u = (blk << 6) + __ffsll((long long)births) - 1;
-      births &= births - 1;
-      if (n_list >= P.F) { atomicMax(P.overflow, 1); continue; }
-      const double* m = MREC(u);
-      create_feature(FREC(kept), new_id++, FLD(m, M_ZR), FLD(m, M_ZPHI), x, y, th, P.qt_r, P.qt_phi, P.p0);
-      ++n_list;
-      ++kept;
-      if (slid) slid = false;                  // it slid into the place of a discarded feature: not visited
-      else { wgt = wgt * P.p0; ++n_assoc; }    // created this step: counts as associated with weight P0
-    }
-  }
-  if (n_assoc == 0) wgt = P.p0;
-  P.nfeat[p] = kept;
-  P.new_id[p] = new_id;
-  P.wout[p] = wgt;
+}
+
+// marks the particles of a list (ancestor indices, selected rows) whose update has not been applied yet
+__global__ void fs_mark_kernel(const int64_t* __restrict__ list, int64_t n, int64_t M, uint8_t* __restrict__ state) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t p = list[i];
+  if (p >= 0 && p < M && state[p] == 0) state[p] = 1;
+}
+__global__ void fs_mark_range_kernel(int64_t lo, int64_t hi, uint8_t* __restrict__ state) {
+  const int64_t p = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < hi && state[p] == 0) state[p] = 1;
 }
 
 // largest feature count over the particles (sizes the update sweep's LDS table of the next step)
@@ -651,13 +714,16 @@ struct FsState {
   std::vector<unsigned long long> h_sect;
   int16_t* d_ints = nullptr; double* d_normals = nullptr; int64_t normals_cap = 0;
   unsigned long long* stage = nullptr; int64_t stage_words = 0;   // feature rows on their way to / from another rank
+  // the step whose weights have been formed and whose updates are applied to particles on request
+  uint8_t* state = nullptr;                       // per particle: 0 update not asked for, 1 asked for, 2 applied
+  FsParams step_params; int step_rows = 0; int step_entry = 1; size_t step_lds = 0; bool step_open = false;
   double std_r = 0.5, std_phi = 3 * M_PI / 180.0, r_max = 10.0, p0 = 0.01, thres_sig = 2.0;
 };
 
 static void fs_free(FsState* s) {
   if (!s) return;
   void* all[] = {s->feat[0], s->feat[1], s->nfeat[0], s->nfeat[1], s->newid[0], s->newid[1], s->meas, s->noise, s->d_truth, s->d_sectors,
-                 s->overflow, s->d_maxfeat, s->d_ints, s->d_normals, s->stage};
+                 s->overflow, s->d_maxfeat, s->d_ints, s->d_normals, s->stage, s->state};
   for (void* q : all) if (q) (void)hipFree(q);
   delete s;
 }
@@ -690,7 +756,32 @@ static int fs_count_features(mclhip_ctx* c, FsState* s, const int32_t* nfeat) {
   return MCLHIP_OK;
 }
 
-// uploads the step's inputs and enqueues the per-particle kernels (pose sample .. weight / decay pass)
+// one launch of the feature sweep of the open step: FS_WEIGH for every particle, FS_APPLY for those marked in s->state
+template <typename IT>
+static int fs_launch_sweep_typed(mclhip_ctx* c, FsState* s, int mode) {
+  const dim3 grid((unsigned)((s->M + 127) / 128));
+  auto* const weigh = fs_update_kernel<IT, FS_WEIGH>;
+  auto* const apply = fs_update_kernel<IT, FS_APPLY>;
+  auto* const k = mode == FS_WEIGH ? weigh : apply;
+  if (s->step_lds > 48 * 1024)
+    F_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->step_lds));
+  hipLaunchKernelGGL(k, grid, dim3(128), s->step_lds, c->stream, s->step_params, s->step_rows, s->state);
+  F_HIP(hipGetLastError());
+  return MCLHIP_OK;
+}
+static int fs_launch_sweep(mclhip_ctx* c, FsState* s, int mode) {
+  return s->step_entry == 1 ? fs_launch_sweep_typed<unsigned char>(c, s, mode) : fs_launch_sweep_typed<unsigned short>(c, s, mode);
+}
+
+// applies the open step's updates to the particles of a list (device pointer to n indices) that have not had them yet
+static int fs_apply_list(mclhip_ctx* c, FsState* s, const int64_t* d_list, int64_t n) {
+  if (!s->step_open || n <= 0) return MCLHIP_OK;
+  hipLaunchKernelGGL(fs_mark_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_list, n, s->M, s->state);
+  F_HIP(hipGetLastError());
+  return fs_launch_sweep(c, s, FS_APPLY);
+}
+
+// uploads the step's inputs and enqueues the kernels that every particle runs (pose sample .. weight)
 static int fs_enqueue_kernel(mclhip_ctx* c, double v, double omega, double dt, const double alpha[6], const double* truth_r,
                              const double* truth_phi, const uint8_t* truth_valid, int L, const int16_t* ints,
                              const double* normals, uint64_t seed) {
@@ -798,17 +889,10 @@ static int fs_enqueue_kernel(mclhip_ctx* c, double v, double omega, double dt, c
     const size_t upd_lds = (size_t)((n_valid + 63) / 64) * 128 * sizeof(unsigned long long) + (size_t)(rows + n_valid) * 128 * entry;
     if (n_valid >= 65535 || upd_lds > 160 * 1024)
       return fail(c, MCLHIP_E_LIMIT, "more features per particle (or landmarks in range) than the update kernel's LDS table holds");
-    if (entry == 1) {
-      if (upd_lds > 48 * 1024)
-        F_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fs_update_kernel<unsigned char>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)upd_lds));
-      hipLaunchKernelGGL(fs_update_kernel<unsigned char>, fs_grid, dim3(128), upd_lds, c->stream, P, rows);
-    } else {
-      if (upd_lds > 48 * 1024)
-        F_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fs_update_kernel<unsigned short>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)upd_lds));
-      hipLaunchKernelGGL(fs_update_kernel<unsigned short>, fs_grid, dim3(128), upd_lds, c->stream, P, rows);
-    }
+    s->step_params = P; s->step_rows = rows; s->step_entry = (int)entry; s->step_lds = upd_lds;
+    F_HIP(hipMemsetAsync(s->state, 0, (size_t)M, c->stream));
+    s->step_open = true;
+    F_TRY(fs_launch_sweep(c, s, FS_WEIGH));       // every particle's weight; the updates follow for those that are drawn
   }
   F_HIP(hipGetLastError());
   return MCLHIP_OK;
@@ -840,6 +924,7 @@ int mclhip_fs_init(mclhip_ctx* c, int64_t M, int capacity) {
   F_HIP(hipMalloc((void**)&s->overflow, sizeof(int32_t)));
   F_HIP(hipMemset(s->overflow, 0, sizeof(int32_t)));
   F_HIP(hipMalloc((void**)&s->d_maxfeat, sizeof(int32_t)));
+  F_HIP(hipMalloc((void**)&s->state, (size_t)M));
   return MCLHIP_OK;
 }
 
@@ -863,7 +948,9 @@ int mclhip_fs_step(mclhip_ctx* c, double v, double omega, double dt, const doubl
   hipLaunchKernelGGL(fs_total_kernel, dim3(1), dim3(64), 0, c->stream, c->cdf_exact, M, 1e-8, c->scal);
   hipLaunchKernelGGL(fs_divide_kernel, dim3(g), dim3(256), 0, c->stream, c->w[c->cur], M, c->scal);
   F_TRY(launch_resample(c, r, MCLHIP_RESAMPLE_PARALLEL)); // flips c->cur; c->idx = ancestors
-  // feature slots follow their ancestors
+  // updates, births and decay of the particles that have descendants; then the feature slots follow their ancestors
+  F_TRY(fs_apply_list(c, s, c->idx, M));
+  s->step_open = false;
   hipLaunchKernelGGL(fs_gather_kernel, dim3(g, s->F), dim3(256), 0, c->stream, c->idx, M, s->F, s->nfeat[a], s->newid[a],
                      s->nfeat[b], s->newid[b], (const double*)s->feat[a], s->feat[b]);
   F_HIP(hipGetLastError());
@@ -885,6 +972,11 @@ int mclhip_fs_get_state(mclhip_ctx* c, double* pose, double* w, int32_t* nfeat, 
   FsState* s = (FsState*)c->fs;
   const int64_t M = s->M;
   const int F = s->F, a = s->cur;
+  if (s->step_open) {                            // between the per-particle kernels and the exchange: every particle's update
+    hipLaunchKernelGGL(fs_mark_range_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, c->stream, (int64_t)0, M, s->state);
+    F_HIP(hipGetLastError());
+    F_TRY(fs_launch_sweep(c, s, FS_APPLY));
+  }
   F_HIP(hipStreamSynchronize(c->stream));
   if (pose || w) F_TRY(mclhip_get_particles(c, pose, w, nullptr));
   std::vector<int32_t> nf(M);
@@ -975,6 +1067,13 @@ int mclhip_fs_shard_pack(mclhip_ctx* c, const int64_t* lo, const int64_t* hi, in
   if (total == 0) return MCLHIP_OK;
   if (!rows) return fail(c, MCLHIP_E_ARG, "rows is NULL");
   F_TRY(fs_stage(c, s, total * words));
+  if (s->step_open) {                           // rows travel with their step's updates applied
+    for (int k = 0; k < nslices; ++k)
+      if (hi[k] > lo[k])
+        hipLaunchKernelGGL(fs_mark_range_kernel, dim3((unsigned)((hi[k] - lo[k] + 255) / 256)), dim3(256), 0, c->stream, lo[k], hi[k], s->state);
+    F_HIP(hipGetLastError());
+    F_TRY(fs_launch_sweep(c, s, FS_APPLY));
+  }
   int64_t off = 0;
   for (int k = 0; k < nslices; ++k) {
     const int64_t n = hi[k] - lo[k];
@@ -1007,6 +1106,7 @@ int mclhip_fs_shard_pack_drawn(mclhip_ctx* c, void* rows) {
   if (!rows) return fail(c, MCLHIP_E_ARG, "rows is NULL");
   if (!c->sel || c->sel_cap < total) return fail(c, MCLHIP_E_STATE, "call mclhip_shard_pack_drawn first (it selects the rows)");
   F_TRY(fs_stage(c, s, total * words));
+  F_TRY(fs_apply_list(c, s, (const int64_t*)c->sel, total));
   hipLaunchKernelGGL(fs_pack_sel_kernel, dim3((unsigned)((total + 63) / 64), s->row_slots + 1), dim3(64), 0, c->stream,
                      (const int64_t*)c->sel, total, s->F, s->row_slots, s->nfeat[s->cur], s->newid[s->cur],
                      (const double*)s->feat[s->cur], s->stage, s->overflow);
@@ -1040,6 +1140,7 @@ int mclhip_fs_shard_unpack(mclhip_ctx* c, const void* rows, int64_t L) {
   F_TRY(fs_count_features(c, s, s->nfeat[b]));
   F_HIP(hipStreamSynchronize(c->stream));
   s->cur = b;
+  s->step_open = false;
   return MCLHIP_OK;
 }
 
