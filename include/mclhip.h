@@ -421,6 +421,9 @@ int mclhip_fs_set_row_slots(mclhip_ctx* ctx, int slots);
 /* Feature rows of the local particles [lo[k], hi[k]) -> rows (host or device memory);
  * between mclhip_fs_shard_kernel and mclhip_fs_shard_unpack with that step's updates applied. */
 int mclhip_fs_shard_pack(mclhip_ctx* ctx, const int64_t* lo, const int64_t* hi, int nslices, void* rows);
+/* After mclhip_shard_pack_drawn: applies the step's updates to the particles it selected and
+ * returns the largest feature count among them (what the ranks agree the row length on). */
+int mclhip_fs_shard_apply_drawn(mclhip_ctx* ctx, int32_t* max_out);
 /* Feature rows of the particles mclhip_shard_pack_drawn selected, in the same order. */
 int mclhip_fs_shard_pack_drawn(mclhip_ctx* ctx, void* rows);
 /* After mclhip_shard_unpack_drawn: every local particle takes the feature slots of its

@@ -105,6 +105,7 @@ PROTOTYPES = {
     "mclhip_fs_max_features": (C.c_int, [_ctx_p, C.POINTER(C.c_int32)]),
     "mclhip_fs_set_row_slots": (C.c_int, [_ctx_p, C.c_int]),
     "mclhip_fs_shard_pack": (C.c_int, [_ctx_p, _i64_p, _i64_p, C.c_int, C.c_void_p]),
+    "mclhip_fs_shard_apply_drawn": (C.c_int, [_ctx_p, C.POINTER(C.c_int32)]),
     "mclhip_fs_shard_pack_drawn": (C.c_int, [_ctx_p, C.c_void_p]),
     "mclhip_fs_shard_unpack": (C.c_int, [_ctx_p, C.c_void_p, C.c_int64]),
     "mclhip_shard_plan_drawn": (C.c_int, [_ctx_p, _i64_p, C.c_int, C.c_int, C.c_double, _i64_p]),
@@ -577,6 +578,12 @@ class Context:
         hi = np.ascontiguousarray(hi, np.int64)
         self._ck(self.lib.mclhip_fs_shard_pack(self.h, _p(lo, _i64_p), _p(hi, _i64_p), len(lo), C.c_void_p(rows_ptr)),
                  "mclhip_fs_shard_pack")
+
+    def fs_shard_apply_drawn(self):
+        """Applies the open step's updates to the rows `shard_pack_drawn` selected; largest feature count among them."""
+        v = C.c_int32()
+        self._ck(self.lib.mclhip_fs_shard_apply_drawn(self.h, C.byref(v)), "mclhip_fs_shard_apply_drawn")
+        return int(v.value)
 
     def fs_shard_pack_drawn(self, rows_ptr):
         self._ck(self.lib.mclhip_fs_shard_pack_drawn(self.h, C.c_void_p(rows_ptr)), "mclhip_fs_shard_pack_drawn")

@@ -57,6 +57,8 @@ struct FsParams {
   double* feat;             // tiles x F x F_WORDS x 64
   double* meas;             // tiles x mcap x M_WORDS x 64
   double* noise;            // [2][M]: largest range / bearing noise a particle drew this step
+  uint16_t* qnoise;         // tiles x mcap x 64: every measurement's noise in steps of sigma/32, two signed bytes (range, bearing)
+  int use_q;                // the association sweep stages qnoise in LDS (it fits)
   double far_r;             // largest noise-free range among the landmarks in range
   const unsigned long long* sectors;   // [blocks of 64 landmarks][kSectors] which landmarks' bearings lie in a sector; then one mask of all per block
   int32_t* overflow;
@@ -247,6 +249,13 @@ __global__ __launch_bounds__(128) void fs_draw_kernel(const FsParams P, const do
         else if (zphi < -M_PI) zphi += 2 * M_PI;
         mr = fmax(mr, fabs(n_r * P.std_r)); mphi = fmax(mphi, fabs(n_phi * P.std_phi));
         const bool in_range = zr <= P.r_max;        // :291
+        // the noise again in a sixteenth of the space: steps of sigma / 32, so that the association sweep can bound
+        // this reading to within sigma / 64 without fetching it.  Bytes: (-128, *) = beyond +-3.9 sigma, no bound;
+        // (*, -128) = out of range, never a candidate.
+        const double s_r = rint(n_r * 32.0), s_phi = rint(n_phi * 32.0);
+        const bool wide = !(fabs(s_r) <= 127.0) || !(fabs(s_phi) <= 127.0);
+        const int b_r = wide ? -128 : (int)s_r, b_phi = !in_range ? -128 : (wide ? 0 : (int)s_phi);
+        P.qnoise[(((p >> 6) * P.mcap + u) << 6) + (p & 63)] = (uint16_t)((b_r & 0xff) | ((b_phi & 0xff) << 8));
         double* m = MREC(u);
         FLD(m, M_ZR) = in_range ? zr : __longlong_as_double(0x7ff8000000000000ll);   // NaN never passes a gate
         FLD(m, M_ZPHI) = zphi;
@@ -276,11 +285,19 @@ __global__ __launch_bounds__(128, FS_WAVES) void fs_associate_kernel(const FsPar
   const int nblk = (nv + 63) >> 6;
   double2* const s_truth = reinterpret_cast<double2*>(fs_assoc_lds);                       // [nv8]
   unsigned long long* const s_sect = reinterpret_cast<unsigned long long*>(s_truth + nv8);  // [nblk][kSectors] + [nblk]
+  uint16_t* const s_q = reinterpret_cast<uint16_t*>(s_sect + nblk * (kSectors + 1));        // [nv][128], this thread's column
   for (int k = threadIdx.x; k < nv8; k += blockDim.x) s_truth[k] = truth[k];
   for (int k = threadIdx.x; k < nblk * (kSectors + 1); k += blockDim.x) s_sect[k] = P.sectors[k];
   __syncthreads();
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P.M) return;
+  const bool use_q = P.use_q != 0;
+  if (use_q) {
+    const uint16_t* q = P.qnoise + (((p >> 6) * P.mcap) << 6) + (p & 63);
+    for (int u = 0; u < nv; ++u) s_q[u * 128 + threadIdx.x] = q[(int64_t)u << 6];
+  }
+  const double q_r = P.std_r * (1.0 / 32.0), q_phi = P.std_phi * (1.0 / 32.0);
+  const double h_r = P.std_r * (1.0 / 64.0) + 1e-9, h_phi = P.std_phi * (1.0 / 64.0) + 1e-9;
   const int n_old = P.nfeat[p];
   if (n_old == 0) return;
   const double x = P.x[p], y = P.y[p], th = P.th[p];
@@ -316,10 +333,20 @@ __global__ __launch_bounds__(128, FS_WAVES) void fs_associate_kernel(const FsPar
         const int k = __ffsll((long long)look) - 1;
         look &= look - 1;
         const double2 t = s_truth[base + k];
-        const double g0 = fmax(fabs(t.x - f.fr) - mr, 0.0);
-        const double d = t.y - f.fphi;
-        const double g1 = fmax(fabs(d - (2.0 * M_PI) * rint(d * (0.5 / M_PI))) - mphi, 0.0);
-        const bool out = (g0 * g0 > lim0) || (g1 * g1 > lim1);
+        // this particle's reading of the landmark: known to sigma / 64 from the staged bytes, else only to within
+        // the largest noise the particle drew
+        double n0 = 0.0, n1 = 0.0, w0 = mr, w1 = mphi;
+        bool never = false;
+        if (use_q) {
+          const int qq = s_q[(base + k) * 128 + threadIdx.x];
+          const int b0 = (int)(signed char)(qq & 0xff), b1 = (int)(signed char)(qq >> 8);
+          never = b1 == -128;
+          if (b0 != -128) { n0 = (double)b0 * q_r; n1 = (double)b1 * q_phi; w0 = h_r; w1 = h_phi; }
+        }
+        const double g0 = fmax(fabs((t.x + n0) - f.fr) - w0, 0.0);
+        const double d = (t.y + n1) - f.fphi;
+        const double g1 = fmax(fabs(d - (2.0 * M_PI) * rint(d * (0.5 / M_PI))) - w1, 0.0);
+        const bool out = never || (g0 * g0 > lim0) || (g1 * g1 > lim1);
         if (!out) cand |= 1ull << k;
       }
       while (cand) {
@@ -593,6 +620,14 @@ __global__ void fs_max_count_kernel(const int32_t* __restrict__ nfeat, int64_t M
   if ((threadIdx.x & 63) == 0) atomicMax(out, v);
 }
 
+// largest feature count among the particles of a list
+__global__ void fs_max_sel_kernel(const int64_t* __restrict__ sel, int64_t n, const int32_t* __restrict__ nfeat, int32_t* __restrict__ out) {
+  int v = 0;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) v = max(v, nfeat[sel[j]]);
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, v);
+}
+
 // feature slots of the drawn ancestors: block row y = slot
 __global__ void fs_gather_kernel(const int64_t* __restrict__ idx, int64_t M, int F, const int32_t* __restrict__ nfeat_in,
                                  const int32_t* __restrict__ newid_in, int32_t* __restrict__ nfeat_out,
@@ -704,6 +739,7 @@ struct FsState {
   int32_t* newid[2] = {nullptr, nullptr};
   double* meas = nullptr; int mcap = 0;   // per-step measurements, mcap rows per tile
   double* noise = nullptr;
+  uint16_t* qnoise = nullptr;
   double* d_truth = nullptr; int truth_cap = 0;   // (r, phi) of the landmarks in range, padded to a multiple of eight
   unsigned long long* d_sectors = nullptr;        // landmark sets per bearing sector and block of 64, then one set of all per block
   int32_t* overflow = nullptr;
@@ -722,7 +758,7 @@ struct FsState {
 
 static void fs_free(FsState* s) {
   if (!s) return;
-  void* all[] = {s->feat[0], s->feat[1], s->nfeat[0], s->nfeat[1], s->newid[0], s->newid[1], s->meas, s->noise, s->d_truth, s->d_sectors,
+  void* all[] = {s->feat[0], s->feat[1], s->nfeat[0], s->nfeat[1], s->newid[0], s->newid[1], s->meas, s->noise, s->qnoise, s->d_truth, s->d_sectors,
                  s->overflow, s->d_maxfeat, s->d_ints, s->d_normals, s->stage, s->state};
   for (void* q : all) if (q) (void)hipFree(q);
   delete s;
@@ -805,11 +841,13 @@ static int fs_enqueue_kernel(mclhip_ctx* c, double v, double omega, double dt, c
     if (s->d_truth) (void)hipFree(s->d_truth);
     if (s->meas) (void)hipFree(s->meas);
     if (s->d_sectors) (void)hipFree(s->d_sectors);
-    s->d_truth = s->meas = nullptr; s->d_sectors = nullptr; s->truth_cap = s->mcap = 0;
+    if (s->qnoise) (void)hipFree(s->qnoise);
+    s->d_truth = s->meas = nullptr; s->d_sectors = nullptr; s->qnoise = nullptr; s->truth_cap = s->mcap = 0;
     const int cap = ((n_valid + n_valid / 4 + 8) + 7) & ~7;
     F_HIP(hipMalloc((void**)&s->d_truth, (size_t)2 * cap * sizeof(double)));
     F_HIP(hipMalloc((void**)&s->d_sectors, (size_t)((cap + 63) / 64) * (kSectors + 1) * sizeof(unsigned long long)));
     F_HIP(hipMalloc((void**)&s->meas, (size_t)s->tiles * cap * M_WORDS * 64 * sizeof(double)));
+    F_HIP(hipMalloc((void**)&s->qnoise, (size_t)s->tiles * cap * 64 * sizeof(uint16_t)));
     s->truth_cap = s->mcap = cap;
   }
   const int n_blk = (n_valid + 63) / 64;
@@ -869,16 +907,19 @@ static int fs_enqueue_kernel(mclhip_ctx* c, double v, double omega, double dt, c
   P.index0 = c->first_index;
   P.x = (double*)c->px[c->cur]; P.y = (double*)c->py[c->cur]; P.th = (double*)c->pth[c->cur]; P.wout = c->w[c->cur];
   P.nfeat = s->nfeat[a]; P.new_id = s->newid[a];
-  P.feat = s->feat[a]; P.meas = s->meas; P.noise = s->noise;
+  P.feat = s->feat[a]; P.meas = s->meas; P.noise = s->noise; P.qnoise = s->qnoise;
   P.overflow = s->overflow;
   P.sectors = s->d_sectors;
   P.far_r = 0.0;
   for (int u = 0; u < n_valid; ++u) P.far_r = std::max(P.far_r, near[2 * u]);
   const dim3 fs_grid((unsigned)((M + 127) / 128));
+  const size_t assoc_tables = near.size() * sizeof(double) + (size_t)n_blk * (kSectors + 1) * sizeof(unsigned long long);
+  const size_t assoc_q = (size_t)n_valid * 128 * sizeof(uint16_t);
+  P.use_q = assoc_tables + assoc_q <= 40 * 1024 ? 1 : 0;      // four blocks per CU keep their columns of quantised noise in LDS
   hipLaunchKernelGGL(fs_pose_kernel, fs_grid, dim3(128), 0, c->stream, P);
   if (n_valid > 0) {
     hipLaunchKernelGGL(fs_draw_kernel, fs_grid, dim3(128), 0, c->stream, P, (const double2*)s->d_truth);
-    const size_t assoc_lds = near.size() * sizeof(double) + (size_t)n_blk * (kSectors + 1) * sizeof(unsigned long long);
+    const size_t assoc_lds = assoc_tables + (P.use_q ? assoc_q : 0);
     if (assoc_lds > 60 * 1024) return fail(c, MCLHIP_E_LIMIT, "more landmarks in range than the association kernel's table holds");
     hipLaunchKernelGGL(fs_associate_kernel, fs_grid, dim3(128), assoc_lds, c->stream, P, (const double2*)s->d_truth);
   }
@@ -1092,6 +1133,26 @@ int mclhip_fs_shard_pack(mclhip_ctx* c, const int64_t* lo, const int64_t* hi, in
     F_HIP(hipMemset(s->overflow, 0, sizeof(int32_t)));
     return fail(c, MCLHIP_E_LIMIT, "a particle holds more features than an exchange row has slots (mclhip_fs_set_row_slots)");
   }
+  return MCLHIP_OK;
+}
+
+int mclhip_fs_shard_apply_drawn(mclhip_ctx* c, int32_t* max_out) {
+  if (!c || !max_out) return MCLHIP_E_ARG;
+  F_HIP(hipSetDevice(c->device));
+  if (!c->fs) return fail(c, MCLHIP_E_STATE, "call mclhip_fs_init first");
+  FsState* s = (FsState*)c->fs;
+  const int64_t total = c->drawn_total;
+  *max_out = 0;
+  if (total == 0) return MCLHIP_OK;
+  if (!c->sel || c->sel_cap < total) return fail(c, MCLHIP_E_STATE, "call mclhip_shard_pack_drawn first (it selects the rows)");
+  F_TRY(fs_apply_list(c, s, (const int64_t*)c->sel, total));
+  F_HIP(hipMemsetAsync(s->d_maxfeat, 0, sizeof(int32_t), c->stream));
+  hipLaunchKernelGGL(fs_max_sel_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 256)), dim3(256), 0, c->stream,
+                     (const int64_t*)c->sel, total, s->nfeat[s->cur], s->d_maxfeat);
+  F_HIP(hipGetLastError());
+  F_HIP(hipMemcpyAsync(max_out, s->d_maxfeat, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  F_HIP(hipStreamSynchronize(c->stream));
+  s->max_feat_valid = false;                     // d_maxfeat no longer holds the count of the whole set
   return MCLHIP_OK;
 }
 

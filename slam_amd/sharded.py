@@ -439,14 +439,17 @@ class ShardedFastSLAM:
         n_send, L = sum(send_counts), sum(recv_counts)
         self.rows_sent_total = getattr(self, "rows_sent_total", 0) + n_send
         self.rows_sent_off_rank = getattr(self, "rows_sent_off_rank", 0) + n_send - send_counts[rank]
-        # feature rows as long as the longest feature list of any rank, not as the capacity
-        most = max(int(np.frombuffer(x, np.int64)[0]) for x in co.allgather_bytes(np.int64(ctx.fs_max_features()).tobytes()))
-        ctx.fs_set_row_slots(max(1, min(most, self.capacity)))
-        self.words = ctx.fs_row_words()
         send = co.rows(n_send, 6)
-        fsend = co.rows(n_send, self.words, co.torch.int64)
+        most_mine = 0
         if n_send:
             ctx.shard_pack_drawn(world, send.data_ptr())
+            most_mine = ctx.fs_shard_apply_drawn()               # :318-404 for the drawn particles only
+        # feature rows as long as the longest feature list that travels, not as the capacity
+        most = max(int(np.frombuffer(x, np.int64)[0]) for x in co.allgather_bytes(np.int64(most_mine).tobytes()))
+        ctx.fs_set_row_slots(max(1, min(most, self.capacity)))
+        self.words = ctx.fs_row_words()
+        fsend = co.rows(n_send, self.words, co.torch.int64)
+        if n_send:
             ctx.fs_shard_pack_drawn(fsend.data_ptr())
         recv = co.all_to_all_rows(send, send_counts, recv_counts)
         frecv = co.all_to_all_rows(fsend, send_counts, recv_counts)
