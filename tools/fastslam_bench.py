@@ -2,6 +2,7 @@
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from slam_amd import _lib as L
 from slam_amd import fast_slam1 as S
 M = int(os.environ.get("FS_M", 1 << 20)); NL = int(os.environ.get("FS_L", 256)); steps = int(os.environ.get("FS_STEPS", 6))
@@ -20,15 +21,23 @@ for t in range(steps):
 nfeat, _ = slam._ctx.fs_feature_counts()
 mean_features = float(nfeat.mean())
 ms = float(np.median(t_all[1:])) * 1e3
-# HBM bytes a step cannot avoid: every live feature slot (64 B) is read and written once by the filter step and
-# read and written once more by the resampling gather
+# The data movement of the reference's step: every live feature slot (64 B) is read and written once by the particle
+# update and once more by the resampling copy.  (This implementation moves less: weights first, updates only for the
+# drawn particles -- see `traffic`, the bytes the kernels of one step actually exchanged with HBM in the profiled run.)
 algo_bytes = M * mean_features * 64.0 * 4
+from profile_facts import latest, traffic_per_step
+src, pmc = latest("fastslam_pmc_per_kernel")
+traffic, per_kernel = (None, None)
+if pmc is not None and (M, NL) == (1 << 20, 256):
+    n_steps = max(c["FETCH_SIZE"]["launches"] for k, c in pmc.items() if "fs_associate" in k and "FETCH_SIZE" in c)
+    traffic, per_kernel = traffic_per_step(pmc, n_steps)
 out = {"metric": "FastSLAM 1.0 particle-steps per second", "particles": M, "landmarks": NL, "value": M / (ms * 1e-3),
        "unit": "particle-steps/s", "ms_per_step": ms, "mean_features": mean_features,
-       "roofline": {"bound": "hbm", "kernel": "whole step (pose, draw, associate, update sweep, resample + gather)",
+       "roofline": {"bound": "hbm", "kernel": "whole step (pose, draw, associate, weigh, resample, update of the drawn, copy)",
                     "achieved": algo_bytes / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                     "frac": algo_bytes / (ms * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_step": algo_bytes,
-                    "traffic": None}}
+                    "traffic": traffic, "traffic_per_kernel": per_kernel, "source": src,
+                    "measured_hbm_frac": None if traffic is None else traffic / (ms * 1e-3) / 8e12}}
 if os.environ.get("FS_CPU", "1") == "1":
     # CPU baseline: the numpy restatement on 64 particles of the same landmark field (one core)
     from oracle import fastslam_oracle as F

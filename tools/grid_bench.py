@@ -2,6 +2,7 @@
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from slam_amd import _lib as L, workload as W
 N = int(os.environ.get("GRID_N", 2048)); D = int(os.environ.get("GRID_D", 72)); steps = int(os.environ.get("GRID_STEPS", 2))
 angles = [0, 15, 30, 45, 60, 75, 90, 345, 330, 315, 300, 285, 270]
@@ -24,11 +25,25 @@ cells = N * N
 pred_ms, upd_ms = msp / max(np_, 1), msu / max(nu, 1)
 free = int(np.count_nonzero(grid >= 200))
 evals = free * D * 13                      # (cell, heading, beam) sector evaluations of one update
+# the update is bound by the rate at which the SIMDs issue its vector instructions: the instruction mix of one launch,
+# priced with the measured issue cost of every opcode (profiles/r*_grid_valu_roofline.json, collected at this
+# configuration), against 1024 SIMDs x 2.4 GHz
+from profile_facts import latest
+src, prof = latest("grid_valu_roofline")
+same = prof is not None and (N, D) == (2048, 72)
+roof = {"kernel": "raycast_kernel GRID mode (update)", "bound": "valu", "unit": "G SIMD issue-cycles/s", "peak": 1024 * 2.4,
+        "achieved": None, "frac": None, "traffic": None, "source": src,
+        "evaluations_per_second": evals / (upd_ms * 1e-3)}
+if same:
+    roof["achieved"] = prof["priced_issue_cycles_per_launch"] / (upd_ms * 1e-3) / 1e9
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    roof["frac_hw_valu_active"] = prof["hardware_valu_active_cycles_per_launch"] / (upd_ms * 1e-3) / 1e9 / roof["peak"]
+    roof["traffic"] = prof["hbm_bytes_per_launch"]
+    roof["hbm"] = {"achieved_GBps": prof["hbm_bytes_per_launch"] / (upd_ms * 1e-3) / 1e9, "peak_GBps": 8000.0,
+                   "frac": prof["hbm_bytes_per_launch"] / (upd_ms * 1e-3) / 1e9 / 8000.0}
 out = {"metric": "grid localisation: (cell, heading) poses per second, predict + update", "grid": [N, N, D],
        "value": cells * D / ((pred_ms + upd_ms) * 1e-3), "unit": "poses/s", "predict_ms": pred_ms, "update_ms": upd_ms,
-       "roofline": {"kernel": "raycast_kernel GRID mode (update)", "bound": "hbm", "unit": "GB/s", "peak": 8000.0,
-                    "achieved": 97.2 * evals / (upd_ms * 1e-3) / 1e9, "frac": 97.2 * evals / (upd_ms * 1e-3) / 1e9 / 8000.0,
-                    "algorithmic_bytes_per_eval": 97.2, "traffic": None},
+       "roofline": roof,
        "predict_roofline": {"kernel": "grid_predict_kernel", "bound": "fp64 vector FMA (dense 7x7xDxD contraction)",
                             "unit": "TFLOP/s", "peak": 78.6, "achieved": 2.0 * cells * D * D * 49 / (pred_ms * 1e-3) / 1e12,
                             "frac": 2.0 * cells * D * D * 49 / (pred_ms * 1e-3) / 1e12 / 78.6}}
