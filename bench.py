@@ -238,16 +238,18 @@ def main():
     import torch
     dist = None
     if world > 1 or a.rehearse_collectives:
+        import datetime
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
+        limit = datetime.timedelta(seconds=300)     # a rank that died leaves the others in a collective: give up, do not hang
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank), timeout=limit)
         elif a.backend == "gloo":
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=limit)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=limit)
     from slam_amd import _lib, workload as W
     from slam_amd.sharded import ShardedFilter
 
@@ -341,10 +343,12 @@ def main():
                                     ("device-driven exchange" if filt.device_path else "host-combined exchange"))
                        if filt.collective else "single GPU"},
             "roofline": roofline(a, M, B, ray_ms, n_ray, copy_gbs),
-            "exchange": ({"rows_per_step_this_rank": filt.rows_sent_total / max(filt.steps_done, 1),
-                          "bytes_between_ranks_per_step_this_rank": 48.0 * filt.rows_sent_off_rank / max(filt.steps_done, 1),
-                          "note": "only rows that some position draws travel (48 B each); one host read per step (the split sizes)"}
-                         if filt.device_path else None),
+            "exchange": ({"rows_per_step_this_rank": getattr(filt, "rows_sent_total", 0) / max(getattr(filt, "steps_done", 0), 1),
+                          "bytes_between_ranks_per_step_this_rank":
+                              48.0 * getattr(filt, "rows_sent_off_rank", 0) / max(getattr(filt, "steps_done", 0), 1),
+                          "host_reads_per_step": 1 if filt.device_path else "host-combined: about 13",
+                          "note": "only rows that some position draws travel (48 B each)"}
+                         if filt.collective else None),
             "kernel_ms": {"raycast": ray_ms, "motion": ms_mot / max(n_mot, 1),
                           "normalise+resample+gather": ms_res / max(n_res, 1)},
         }

@@ -4,10 +4,10 @@ and beam table replicated.
 Only small per-rank results cross ranks as collectives -- the largest log-weight (all-reduce
 max), the sums of the 8192-element chunks (all-gather; every rank then adds them left to right,
 so the global sum is bit-equal to np.sum of the whole vector on every rank), the integer totals
-and the short irregular-record lists of the order-exact scan (all-gather), and the counts that
-turn the 2*world shard-boundary positions into global source indices (all-reduce sum) --
-followed by one all-to-all of contiguous row slices: since resample indices are monotone, the
-positions a rank owns draw from one contiguous range of source particles.
+and the short irregular-record lists of the order-exact scan (all-gather), and the number of rows
+every rank sends to every other (all-gather) -- followed by one all-to-all of rows.  Only rows that
+some position draws travel (mc_localization.py:253-259 reads X[i] only for the drawn i): a rank
+finds, from its exact running sums, the range of positions that draw each of its rows.
 
 The arithmetic of every step lives behind a `backend` (the C ABI in production); this file is
 the cross-rank bookkeeping, and it is the same code under RCCL (GPU tensors) and gloo (CPU
@@ -50,15 +50,16 @@ class HipShardBackend:
     def finalize(self, all_records, p_off, f_off):
         self.ctx.shard_finalize(all_records, p_off, f_off)
 
-    def count_below(self, U):
-        return self.ctx.shard_count_below(U)
+    def plan_drawn(self, firsts, rank, r):
+        """Number of drawn local rows every rank needs."""
+        return self.ctx.shard_plan_drawn(firsts, rank, r)
 
-    def pack(self, lo, hi, rows):
-        """rows: torch tensor [n,5] float64 (GPU or CPU) that receives the packed slices."""
-        self.ctx.shard_pack(lo, hi, rows.data_ptr())
+    def pack_drawn(self, world, rows):
+        """rows: torch tensor [n,6] float64 (GPU or CPU) that receives the drawn rows, destination after destination."""
+        self.ctx.shard_pack_drawn(world, rows.data_ptr())
 
-    def unpack_resample(self, rows, L, r, row0_global, want_idx):
-        return self.ctx.shard_unpack_resample(rows.data_ptr(), L, r, row0_global, want_idx)
+    def unpack_drawn(self, rows, L, r, want_idx):
+        return self.ctx.shard_unpack_drawn(rows.data_ptr(), L, r, want_idx)
 
     def step_single(self, v, omega, dt, alpha, z_meas, r, noise_ints, seed, mode, wait):
         self.ctx.step(v, omega, dt, alpha, z_meas, r, noise_ints, seed, mode, wait=wait)
@@ -260,25 +261,6 @@ class ShardedFilter:
         self._keep = (send, recv)       # alive until the next step has been enqueued behind them
         return True
 
-    def _plan(self, gidx):
-        """Row slices to send to / receive from every rank, from the global source indices of every
-        rank's first and last position."""
-        rank, world = self.rank, self.world
-        glo, ghi = gidx[0::2], gidx[1::2]
-        my_lo, my_hi = self.firsts[rank], self.firsts[rank + 1] - 1
-        lo, hi, send_counts = [], [], []
-        for d in range(world):          # what this rank sends to d
-            a, z = max(int(glo[d]), my_lo), min(int(ghi[d]), my_hi)
-            n = max(0, z - a + 1)
-            send_counts.append(n)
-            lo.append(a - my_lo if n else 0)
-            hi.append(z - my_lo + 1 if n else 0)
-        recv_counts = []
-        for s in range(world):          # what this rank receives from s
-            a, z = max(int(glo[rank]), self.firsts[s]), min(int(ghi[rank]), self.firsts[s + 1] - 1)
-            recv_counts.append(max(0, z - a + 1))
-        return lo, hi, send_counts, recv_counts, glo
-
     def _drive(self, gen):
         """Serve the exchanges of one rank's _device_step with torch.distributed on the step's stream."""
         torch, dist = self._torch, self.dist
@@ -357,20 +339,20 @@ class ShardedFilter:
             rs["P"] = rs["P"] + np.uint64(p_off[s])  # wraps modulo 2^64 like the device prefix
             glob.append(rs)
         b.finalize(np.concatenate(glob), p_off[rank], f_off[rank])
-        # global source index of the first and last position of every rank
-        M = self.m_total
-        m_edge = []
-        for d in range(world):
-            m_edge += [self.firsts[d], self.firsts[d + 1] - 1]
-        U = np.array([r + (m / M) for m in m_edge], np.float64)   # mc_localization.py:254
-        gidx = np.minimum(co.allreduce_sum_i64(b.count_below(U)), M - 1)
-        lo, hi, send_counts, recv_counts, glo = self._plan(gidx)
-        send = co.rows(sum(send_counts))
-        if sum(send_counts):
-            b.pack(lo, hi, send)
+        # only the rows that some position draws travel: counts per destination, agreed over the ranks
+        mine = b.plan_drawn(self.firsts, rank, r)
+        counts = np.stack([np.frombuffer(x, np.int64) for x in co.allgather_bytes(np.asarray(mine, np.int64).tobytes())])
+        send_counts = [int(c) for c in counts[rank]]          # [source, destination]
+        recv_counts = [int(c) for c in counts[:, rank]]
+        n_send, L = sum(send_counts), sum(recv_counts)
+        self.rows_sent_total = getattr(self, "rows_sent_total", 0) + n_send
+        self.rows_sent_off_rank = getattr(self, "rows_sent_off_rank", 0) + n_send - send_counts[rank]
+        self.steps_done = getattr(self, "steps_done", 0) + 1
+        send = co.rows(n_send, 6)
+        if n_send:
+            b.pack_drawn(world, send)
         recv = co.all_to_all_rows(send, send_counts, recv_counts)
-        L = int(sum(recv_counts))
-        self.last_idx = b.unpack_resample(recv, L, r, int(glo[rank]), want_idx)
+        self.last_idx = b.unpack_drawn(recv, L, r, want_idx)
 
 
 class ShardedFastSLAM:
@@ -395,7 +377,6 @@ class ShardedFastSLAM:
         ctx.shard_set(self.firsts[rank], self.m_total)
         self.words = ctx.fs_row_words()
         self.last_idx = None
-        self._plan = ShardedFilter._plan.__get__(self)   # same slicing rule as the particle filter
 
     def _exact_running_sums(self, divisor, all_chunks):
         """w /= divisor on every rank, then the strictly sequential running sum of the GLOBAL weight

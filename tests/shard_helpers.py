@@ -74,24 +74,40 @@ class NumpyShardBackend:
         c = np.cumsum(all_records["w"])
         self.cdf = c[f_off:f_off + len(self.w)]
 
-    def count_below(self, U):
-        return np.searchsorted(self.cdf, U, side="left").astype(np.int64)
+    def plan_drawn(self, firsts, rank, r):
+        """Which local rows some position draws, and the positions of which rank: row j is drawn by the positions
+        [G[j-1], G[j]), G[j] = first position m with U_m = r + m/M above the row's running sum (the walk's own
+        comparison); a rank's first row always counts as drawn (its predecessor's running sum lives elsewhere), the
+        globally last row keeps every position to the end."""
+        M, n, world = self.m_total, len(self.cdf), len(firsts) - 1
+        U = r + (np.arange(M) / M)
+        G = np.searchsorted(U, self.cdf, side="right").astype(np.int64)
+        if rank == world - 1:
+            G[-1] = M
+        drawn = np.ones(n, bool)
+        drawn[1:] = G[1:] > G[:-1]
+        self._sel = []
+        for d in range(world):
+            jl = int(np.searchsorted(G, firsts[d], side="right"))
+            jh = min(int(np.searchsorted(G, firsts[d + 1] - 1, side="right")), n - 1)
+            rows = [j for j in range(jl, jh + 1) if drawn[j]] if firsts[d + 1] > firsts[d] else []
+            self._sel.append(np.array(rows, np.int64))
+        return np.array([len(x) for x in self._sel], np.int64)
 
-    def pack(self, lo, hi, rows):
-        out = []
-        for a, z in zip(lo, hi):
-            out.append(np.concatenate([self.X[a:z], self.w[a:z, None], self.cdf[a:z, None]], 1))
-        out = np.concatenate(out, 0)
+    def pack_drawn(self, world, rows):
+        sel = np.concatenate(self._sel)
+        gid = (self.first + sel).astype(np.int64).view(np.float64)
+        out = np.concatenate([self.X[sel], self.w[sel, None], self.cdf[sel, None], gid[:, None]], 1)
         rows[:len(out)] = __import__("torch").from_numpy(out)
 
-    def unpack_resample(self, rows, L, r, row0_global, want_idx):
+    def unpack_drawn(self, rows, L, r, want_idx):
         R = rows[:L].numpy()
         m = self.first + np.arange(len(self.X))
         U = r + (m / self.m_total)
         j = np.minimum(np.searchsorted(R[:, 4], U, side="left"), L - 1)
         self.X = R[j, :3].copy()
         self.w = R[j, 3].copy()
-        return row0_global + j
+        return np.ascontiguousarray(R[j, 5]).view(np.int64)
 
 
 def run_ranks(fn, world, *args, backend="gloo"):
