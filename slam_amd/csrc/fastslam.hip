@@ -283,10 +283,13 @@ __global__ __launch_bounds__(128, FS_WAVES) void fs_associate_kernel(const FsPar
   const int nv = P.L;
   const int nv8 = (nv + 7) & ~7;                // the table is padded to a multiple of eight with far-away readings
   const int nblk = (nv + 63) >> 6;
-  double2* const s_truth = reinterpret_cast<double2*>(fs_assoc_lds);                       // [nv8]
-  unsigned long long* const s_sect = reinterpret_cast<unsigned long long*>(s_truth + nv8);  // [nblk][kSectors] + [nblk]
-  uint16_t* const s_q = reinterpret_cast<uint16_t*>(s_sect + nblk * (kSectors + 1));        // [nv][128], this thread's column
-  for (int k = threadIdx.x; k < nv8; k += blockDim.x) s_truth[k] = truth[k];
+  unsigned long long* const s_sect = reinterpret_cast<unsigned long long*>(fs_assoc_lds);   // [nblk][kSectors] + [nblk]
+  float2* const s_tf = reinterpret_cast<float2*>(s_sect + nblk * (kSectors + 1));            // [nv8] noise-free (r, phi) of the landmarks, float32
+  uint16_t* const s_q = reinterpret_cast<uint16_t*>(s_tf + nv8);                            // [nv][128], this thread's column
+  for (int k = threadIdx.x; k < nv8; k += blockDim.x) {
+    const double2 t = truth[k];
+    s_tf[k] = make_float2((float)t.x, (float)t.y);
+  }
   for (int k = threadIdx.x; k < nblk * (kSectors + 1); k += blockDim.x) s_sect[k] = P.sectors[k];
   __syncthreads();
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -296,13 +299,19 @@ __global__ __launch_bounds__(128, FS_WAVES) void fs_associate_kernel(const FsPar
     const uint16_t* q = P.qnoise + (((p >> 6) * P.mcap) << 6) + (p & 63);
     for (int u = 0; u < nv; ++u) s_q[u * 128 + threadIdx.x] = q[(int64_t)u << 6];
   }
-  const double q_r = P.std_r * (1.0 / 32.0), q_phi = P.std_phi * (1.0 / 32.0);
-  const double h_r = P.std_r * (1.0 / 64.0) + 1e-9, h_phi = P.std_phi * (1.0 / 64.0) + 1e-9;
+  // The cheap test runs in float32: it only has to keep every pair that can pass the gate, it uses twice the gate,
+  // and what float32 rounding can move (a few units in the seventh digit of a range, 1e-6 rad) is added to the
+  // widths below; the close test that follows is the reference's float64 arithmetic.
+  const float q_r = (float)(P.std_r * (1.0 / 32.0)), q_phi = (float)(P.std_phi * (1.0 / 32.0));
+  const float h_phi = (float)(P.std_phi * (1.0 / 64.0)) + 1e-5f;
+  const float h_r0 = (float)(P.std_r * (1.0 / 64.0)), far_rf = (float)P.far_r * 1.00001f + 1e-4f;
   const int n_old = P.nfeat[p];
   if (n_old == 0) return;
   const double x = P.x[p], y = P.y[p], th = P.th[p];
   const double mr = P.noise[p], mphi = P.noise[P.M + p];
+  const float mrf = (float)mr * 1.00001f + 1e-6f, mphif = (float)mphi * 1.00001f + 1e-5f;
   const double two_gate = 2.0 * P.gate2;
+  const float two_gatef = (float)two_gate * 1.00001f;
   const double inv_sector = (double)kSectors / (2.0 * M_PI);
   constexpr int kBatch = FS_BATCH;
   RawFeat next = load_raw(FREC(0));
@@ -313,12 +322,17 @@ __global__ __launch_bounds__(128, FS_WAVES) void fs_associate_kernel(const FsPar
       // no reading can pass the range gate of a feature that lies further out than the farthest landmark in
       // range + this particle's largest range noise + the gate of the largest range variance the feature can
       // have (|h' C h| <= sum |C_ij| for a unit h): such a feature needs no prediction at all
-      const double dx = raw.m0 - x, dy = raw.m1 - y;
-      const double q_cap = (fabs(raw.c00) + fabs(raw.c01)) + (fabs(raw.c10) + fabs(raw.c11)) + P.qt_r;
-      if (sqrt(dx * dx + dy * dy) - (P.far_r + mr) > sqrt(two_gate * q_cap) + 1e-9) continue;
+      // (float32 with every bound rounded outwards: a feature skipped here is far beyond the gate)
+      const float dx = (float)(raw.m0 - x), dy = (float)(raw.m1 - y);
+      const float q_cap = (fabsf((float)raw.c00) + fabsf((float)raw.c01)) + (fabsf((float)raw.c10) + fabsf((float)raw.c11)) + (float)P.qt_r;
+      const float lim = (far_rf + mrf) + sqrtf(two_gatef * q_cap) * 1.00001f;
+      if ((dx * dx + dy * dy) * 0.9999f > lim * lim) continue;
     }
     const Predicted f = predict_feature(raw, x, y, th, P.qt_r, P.qt_phi, nullptr);
     const double lim0 = two_gate * (f.q11 * f.dq), lim1 = two_gate * (f.q00 * f.dq);
+    const float lim0f = (float)lim0 * 1.0001f, lim1f = (float)lim1 * 1.0001f;      // NaN: nothing is out, the close test decides
+    const float ffr = (float)f.fr, ffphi = (float)f.fphi;
+    const float h_r = h_r0 + 2e-6f * (fabsf(ffr) + far_rf + 1.0f);                 // float32 rounding of ranges this large
     // a reading can pass only if its noise-free bearing is within `reach` of the predicted one on the circle
     const double reach = mphi + sqrt(lim1) + 1e-6;
     const bool everything = !(fabs(f.fphi) < 1.0e6) || !(reach < 3.0);   // also NaN
@@ -332,21 +346,21 @@ __global__ __launch_bounds__(128, FS_WAVES) void fs_associate_kernel(const FsPar
       while (look) {
         const int k = __ffsll((long long)look) - 1;
         look &= look - 1;
-        const double2 t = s_truth[base + k];
+        const float2 t = s_tf[base + k];
         // this particle's reading of the landmark: known to sigma / 64 from the staged bytes, else only to within
         // the largest noise the particle drew
-        double n0 = 0.0, n1 = 0.0, w0 = mr, w1 = mphi;
+        float n0 = 0.0f, n1 = 0.0f, w0 = mrf, w1 = mphif;
         bool never = false;
         if (use_q) {
           const int qq = s_q[(base + k) * 128 + threadIdx.x];
           const int b0 = (int)(signed char)(qq & 0xff), b1 = (int)(signed char)(qq >> 8);
           never = b1 == -128;
-          if (b0 != -128) { n0 = (double)b0 * q_r; n1 = (double)b1 * q_phi; w0 = h_r; w1 = h_phi; }
+          if (b0 != -128) { n0 = (float)b0 * q_r; n1 = (float)b1 * q_phi; w0 = h_r; w1 = h_phi; }
         }
-        const double g0 = fmax(fabs((t.x + n0) - f.fr) - w0, 0.0);
-        const double d = (t.y + n1) - f.fphi;
-        const double g1 = fmax(fabs(d - (2.0 * M_PI) * rint(d * (0.5 / M_PI))) - w1, 0.0);
-        const bool out = never || (g0 * g0 > lim0) || (g1 * g1 > lim1);
+        const float g0 = fmaxf(fabsf((t.x + n0) - ffr) - w0, 0.0f);
+        const float d = (t.y + n1) - ffphi;
+        const float g1 = fmaxf(fabsf(d - 6.2831853f * rintf(d * 0.15915494f)) - w1, 0.0f);
+        const bool out = never || (g0 * g0 > lim0f) || (g1 * g1 > lim1f);
         if (!out) cand |= 1ull << k;
       }
       while (cand) {
@@ -913,7 +927,7 @@ static int fs_enqueue_kernel(mclhip_ctx* c, double v, double omega, double dt, c
   P.far_r = 0.0;
   for (int u = 0; u < n_valid; ++u) P.far_r = std::max(P.far_r, near[2 * u]);
   const dim3 fs_grid((unsigned)((M + 127) / 128));
-  const size_t assoc_tables = near.size() * sizeof(double) + (size_t)n_blk * (kSectors + 1) * sizeof(unsigned long long);
+  const size_t assoc_tables = (size_t)n_blk * (kSectors + 1) * sizeof(unsigned long long) + near.size() / 2 * sizeof(float2);
   const size_t assoc_q = (size_t)n_valid * 128 * sizeof(uint16_t);
   P.use_q = assoc_tables + assoc_q <= 40 * 1024 ? 1 : 0;      // four blocks per CU keep their columns of quantised noise in LDS
   hipLaunchKernelGGL(fs_pose_kernel, fs_grid, dim3(128), 0, c->stream, P);
