@@ -56,9 +56,7 @@ struct FsParams {
   int32_t *nfeat, *new_id;
   double* feat;             // tiles x F x F_WORDS x 64
   double* meas;             // tiles x mcap x M_WORDS x 64
-  double* noise;            // [2][M]: largest range / bearing noise a particle drew this step
-  uint16_t* qnoise;         // tiles x mcap x 64: every measurement's noise in steps of sigma/32, two signed bytes (range, bearing)
-  int use_q;                // the association sweep stages qnoise in LDS (it fits)
+  int use_q;                // the association sweep keeps every measurement's noise in steps of sigma/32 in LDS (it fits)
   double far_r;             // largest noise-free range among the landmarks in range
   const unsigned long long* sectors;   // [blocks of 64 landmarks][kSectors] which landmarks' bearings lie in a sector; then one mask of all per block
   int32_t* overflow;
@@ -212,7 +210,8 @@ __device__ __attribute__((noinline)) void create_feature(double* f, int32_t id, 
 // ---- every landmark: draw the measurement, associate, create or update (:286-375) ----
 // The association of a measurement reads only the prediction of the features that existed before this
 // step, never what an earlier measurement of the same step changed.  So all measurements of the step are
-// drawn first and parked in device memory (fs_draw_kernel), ONE sweep over the stored features associates
+// drawn first and parked in device memory (draw_measurements, at the head of the association kernel: the stores
+// drain while it computes), ONE sweep over the stored features associates
 // them all (fs_associate_kernel), and then they are applied (fs_update_kernel): updates feature by feature
 // -- two measurements may pick the same feature: they are applied one after the other, in landmark order,
 // with the one prediction -- and births in landmark order; an update touches a feature that existed
@@ -222,10 +221,11 @@ __device__ __attribute__((noinline)) void create_feature(double* f, int32_t id, 
 // trips: loads a step ahead of their use, stores that nothing waits for, out-of-line calls (which drain
 // the memory queue) only where nothing is in flight.
 
-// one noisy measurement per landmark in range (:145-152) and the largest noise of this particle
-__global__ __launch_bounds__(128) void fs_draw_kernel(const FsParams P, const double2* __restrict__ truth) {
-  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P.M) return;
+// one noisy measurement per landmark in range (:145-152), parked in device memory for the sweeps that follow; returns
+// the largest range / bearing noise this particle drew.  s_q (nullable): this thread's column of the noise in steps
+// of sigma / 32, two signed bytes per measurement.
+__device__ inline void draw_measurements(const FsParams& P, int64_t p, const double2* __restrict__ truth, uint16_t* s_q,
+                                         double* mr_out, double* mphi_out) {
   const int nv = P.L;
   const double* normals = P.normals ? P.normals + p * P.n_norm : nullptr;
   double mr = 0.0, mphi = 0.0;
@@ -249,13 +249,15 @@ __global__ __launch_bounds__(128) void fs_draw_kernel(const FsParams P, const do
         else if (zphi < -M_PI) zphi += 2 * M_PI;
         mr = fmax(mr, fabs(n_r * P.std_r)); mphi = fmax(mphi, fabs(n_phi * P.std_phi));
         const bool in_range = zr <= P.r_max;        // :291
-        // the noise again in a sixteenth of the space: steps of sigma / 32, so that the association sweep can bound
-        // this reading to within sigma / 64 without fetching it.  Bytes: (-128, *) = beyond +-3.9 sigma, no bound;
-        // (*, -128) = out of range, never a candidate.
-        const double s_r = rint(n_r * 32.0), s_phi = rint(n_phi * 32.0);
-        const bool wide = !(fabs(s_r) <= 127.0) || !(fabs(s_phi) <= 127.0);
-        const int b_r = wide ? -128 : (int)s_r, b_phi = !in_range ? -128 : (wide ? 0 : (int)s_phi);
-        P.qnoise[(((p >> 6) * P.mcap + u) << 6) + (p & 63)] = (uint16_t)((b_r & 0xff) | ((b_phi & 0xff) << 8));
+        if (s_q) {
+          // the noise again in a sixteenth of the space: steps of sigma / 32, so that the association sweep can bound
+          // this reading to within sigma / 64 without fetching it.  Bytes: (-128, *) = beyond +-3.9 sigma, no bound;
+          // (*, -128) = out of range, never a candidate.
+          const double s_r = rint(n_r * 32.0), s_phi = rint(n_phi * 32.0);
+          const bool wide = !(fabs(s_r) <= 127.0) || !(fabs(s_phi) <= 127.0);
+          const int b_r = wide ? -128 : (int)s_r, b_phi = !in_range ? -128 : (wide ? 0 : (int)s_phi);
+          s_q[u * 128] = (uint16_t)((b_r & 0xff) | ((b_phi & 0xff) << 8));
+        }
         double* m = MREC(u);
         FLD(m, M_ZR) = in_range ? zr : __longlong_as_double(0x7ff8000000000000ll);   // NaN never passes a gate
         FLD(m, M_ZPHI) = zphi;
@@ -264,8 +266,8 @@ __global__ __launch_bounds__(128) void fs_draw_kernel(const FsParams P, const do
       }
     }
   }
-  P.noise[p] = mr;
-  P.noise[P.M + p] = mphi;
+  *mr_out = mr;
+  *mphi_out = mphi;
 }
 
 // The sweep looks at a (feature, measurement) pair closely only if it can pass the gate at all.  For a
@@ -295,10 +297,9 @@ __global__ __launch_bounds__(128, FS_WAVES) void fs_associate_kernel(const FsPar
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P.M) return;
   const bool use_q = P.use_q != 0;
-  if (use_q) {
-    const uint16_t* q = P.qnoise + (((p >> 6) * P.mcap) << 6) + (p & 63);
-    for (int u = 0; u < nv; ++u) s_q[u * 128 + threadIdx.x] = q[(int64_t)u << 6];
-  }
+  // the measurements first: their stores drain while the sweep below computes (a thread reads back only its own)
+  double mr, mphi;
+  draw_measurements(P, p, truth, use_q ? s_q + threadIdx.x : nullptr, &mr, &mphi);
   // The cheap test runs in float32: it only has to keep every pair that can pass the gate, it uses twice the gate,
   // and what float32 rounding can move (a few units in the seventh digit of a range, 1e-6 rad) is added to the
   // widths below; the close test that follows is the reference's float64 arithmetic.
@@ -308,7 +309,6 @@ __global__ __launch_bounds__(128, FS_WAVES) void fs_associate_kernel(const FsPar
   const int n_old = P.nfeat[p];
   if (n_old == 0) return;
   const double x = P.x[p], y = P.y[p], th = P.th[p];
-  const double mr = P.noise[p], mphi = P.noise[P.M + p];
   const float mrf = (float)mr * 1.00001f + 1e-6f, mphif = (float)mphi * 1.00001f + 1e-5f;
   const double two_gate = 2.0 * P.gate2;
   const float two_gatef = (float)two_gate * 1.00001f;
@@ -752,8 +752,6 @@ struct FsState {
   int32_t* nfeat[2] = {nullptr, nullptr};
   int32_t* newid[2] = {nullptr, nullptr};
   double* meas = nullptr; int mcap = 0;   // per-step measurements, mcap rows per tile
-  double* noise = nullptr;
-  uint16_t* qnoise = nullptr;
   double* d_truth = nullptr; int truth_cap = 0;   // (r, phi) of the landmarks in range, padded to a multiple of eight
   unsigned long long* d_sectors = nullptr;        // landmark sets per bearing sector and block of 64, then one set of all per block
   int32_t* overflow = nullptr;
@@ -772,7 +770,7 @@ struct FsState {
 
 static void fs_free(FsState* s) {
   if (!s) return;
-  void* all[] = {s->feat[0], s->feat[1], s->nfeat[0], s->nfeat[1], s->newid[0], s->newid[1], s->meas, s->noise, s->qnoise, s->d_truth, s->d_sectors,
+  void* all[] = {s->feat[0], s->feat[1], s->nfeat[0], s->nfeat[1], s->newid[0], s->newid[1], s->meas, s->d_truth, s->d_sectors,
                  s->overflow, s->d_maxfeat, s->d_ints, s->d_normals, s->stage, s->state};
   for (void* q : all) if (q) (void)hipFree(q);
   delete s;
@@ -855,13 +853,11 @@ static int fs_enqueue_kernel(mclhip_ctx* c, double v, double omega, double dt, c
     if (s->d_truth) (void)hipFree(s->d_truth);
     if (s->meas) (void)hipFree(s->meas);
     if (s->d_sectors) (void)hipFree(s->d_sectors);
-    if (s->qnoise) (void)hipFree(s->qnoise);
-    s->d_truth = s->meas = nullptr; s->d_sectors = nullptr; s->qnoise = nullptr; s->truth_cap = s->mcap = 0;
+    s->d_truth = s->meas = nullptr; s->d_sectors = nullptr; s->truth_cap = s->mcap = 0;
     const int cap = ((n_valid + n_valid / 4 + 8) + 7) & ~7;
     F_HIP(hipMalloc((void**)&s->d_truth, (size_t)2 * cap * sizeof(double)));
     F_HIP(hipMalloc((void**)&s->d_sectors, (size_t)((cap + 63) / 64) * (kSectors + 1) * sizeof(unsigned long long)));
     F_HIP(hipMalloc((void**)&s->meas, (size_t)s->tiles * cap * M_WORDS * 64 * sizeof(double)));
-    F_HIP(hipMalloc((void**)&s->qnoise, (size_t)s->tiles * cap * 64 * sizeof(uint16_t)));
     s->truth_cap = s->mcap = cap;
   }
   const int n_blk = (n_valid + 63) / 64;
@@ -921,7 +917,7 @@ static int fs_enqueue_kernel(mclhip_ctx* c, double v, double omega, double dt, c
   P.index0 = c->first_index;
   P.x = (double*)c->px[c->cur]; P.y = (double*)c->py[c->cur]; P.th = (double*)c->pth[c->cur]; P.wout = c->w[c->cur];
   P.nfeat = s->nfeat[a]; P.new_id = s->newid[a];
-  P.feat = s->feat[a]; P.meas = s->meas; P.noise = s->noise; P.qnoise = s->qnoise;
+  P.feat = s->feat[a]; P.meas = s->meas;
   P.overflow = s->overflow;
   P.sectors = s->d_sectors;
   P.far_r = 0.0;
@@ -932,7 +928,6 @@ static int fs_enqueue_kernel(mclhip_ctx* c, double v, double omega, double dt, c
   P.use_q = assoc_tables + assoc_q <= 40 * 1024 ? 1 : 0;      // four blocks per CU keep their columns of quantised noise in LDS
   hipLaunchKernelGGL(fs_pose_kernel, fs_grid, dim3(128), 0, c->stream, P);
   if (n_valid > 0) {
-    hipLaunchKernelGGL(fs_draw_kernel, fs_grid, dim3(128), 0, c->stream, P, (const double2*)s->d_truth);
     const size_t assoc_lds = assoc_tables + (P.use_q ? assoc_q : 0);
     if (assoc_lds > 60 * 1024) return fail(c, MCLHIP_E_LIMIT, "more landmarks in range than the association kernel's table holds");
     hipLaunchKernelGGL(fs_associate_kernel, fs_grid, dim3(128), assoc_lds, c->stream, P, (const double2*)s->d_truth);
@@ -975,7 +970,6 @@ int mclhip_fs_init(mclhip_ctx* c, int64_t M, int capacity) {
     F_HIP(hipMemset(s->nfeat[b], 0, M * sizeof(int32_t)));
     F_HIP(hipMemset(s->newid[b], 0, M * sizeof(int32_t)));
   }
-  F_HIP(hipMalloc((void**)&s->noise, (size_t)2 * M * sizeof(double)));
   F_HIP(hipMalloc((void**)&s->overflow, sizeof(int32_t)));
   F_HIP(hipMemset(s->overflow, 0, sizeof(int32_t)));
   F_HIP(hipMalloc((void**)&s->d_maxfeat, sizeof(int32_t)));
