@@ -55,6 +55,7 @@ struct FsParams {
   double *x, *y, *th, *wout;
   int32_t *nfeat, *new_id;
   double* feat;             // tiles x F x F_WORDS x 64
+  const uint8_t* shared_tile;   // per tile of `feat`: 1 = the slots of all its particles stand once, in lane 0's region
   double* meas;             // tiles x mcap x M_WORDS x 64
   int use_q;                // the association sweep keeps every measurement's noise in steps of sigma/32 in LDS (it fits)
   double far_r;             // largest noise-free range among the landmarks in range
@@ -68,8 +69,16 @@ __device__ __host__ inline int64_t tile_word(int64_t p, int64_t rows, int64_t ro
   return ((((p >> 6) * rows + row) * words) << 6) + ((p & 63) << 1);
 }
 #define FLD(rec, f) (rec)[((f) >> 1) * 128 + ((f) & 1)]
-#define FREC(slot) (P.feat + tile_word(p, P.F, (slot), F_WORDS))
-#define MREC(u) (P.meas + tile_word(p, P.mcap, (u), M_WORDS))
+// `pf`: the particle whose region of the tile holds this particle's slots (itself, or lane 0 of a shared tile);
+// `pm`: the particle whose measurements are meant
+#define FREC(slot) (P.feat + tile_word(pf, P.F, (slot), F_WORDS))
+#define MREC(u) (P.meas + tile_word(pm, P.mcap, (u), M_WORDS))
+// After resampling, the 64 particles of a tile often descend from ONE ancestor (with hundreds of landmarks a few
+// hundred ancestors feed a million particles): their feature slots are then identical, the tile keeps one copy -- in
+// the region of its lane 0 -- and says so in a byte per tile.  Every lane of such a tile reads the same addresses.
+__device__ inline int64_t slot_owner(const uint8_t* __restrict__ shared_tile, int64_t p) {
+  return shared_tile[p >> 6] ? (p & ~(int64_t)63) : p;
+}
 #define FLD_I(rec, f, half) ((int32_t*)&FLD(rec, f))[half]   // 32-bit halves of a word
 
 struct M2 { double a, b, c, d; };   // [[a, b], [c, d]]
@@ -227,6 +236,7 @@ __device__ __attribute__((noinline)) void create_feature(double* f, int32_t id, 
 __device__ inline void draw_measurements(const FsParams& P, int64_t p, const double2* __restrict__ truth, uint16_t* s_q,
                                          double* mr_out, double* mphi_out) {
   const int nv = P.L;
+  const int64_t pm = p;
   const double* normals = P.normals ? P.normals + p * P.n_norm : nullptr;
   double mr = 0.0, mphi = 0.0;
   for (int u0 = 0; u0 < nv; u0 += 2) {
@@ -308,6 +318,7 @@ __global__ __launch_bounds__(128, FS_WAVES) void fs_associate_kernel(const FsPar
   const float h_r0 = (float)(P.std_r * (1.0 / 64.0)), far_rf = (float)P.far_r * 1.00001f + 1e-4f;
   const int n_old = P.nfeat[p];
   if (n_old == 0) return;
+  const int64_t pm = p, pf = slot_owner(P.shared_tile, p);
   const double x = P.x[p], y = P.y[p], th = P.th[p];
   const float mrf = (float)mr * 1.00001f + 1e-6f, mphif = (float)mphi * 1.00001f + 1e-5f;
   const double two_gate = 2.0 * P.gate2;
@@ -452,21 +463,44 @@ __device__ inline void ekf_update(Slot& d, const Predicted& pr, const M2& H, dou
 // IT: unsigned char while fewer than 255 measurements are in range, else unsigned short.
 // Dynamic LDS: births [blocks of 64 measurements][128] u64, then the inverse [rows][128] IT, rows >= every
 // particle's feature count, then the chains [measurements][128] IT.
-enum { FS_WEIGH = 0, FS_APPLY = 1 };
+enum { FS_WEIGH = 0, FS_APPLY = 1, FS_COPY = 2 };
+// Where FS_COPY writes: the other buffer of the resampled set.
+struct FsDest {
+  const int64_t* idx;       // ancestor of every position
+  double* feat;
+  int32_t *nfeat, *new_id;
+  uint8_t* shared_tile;
+};
 template <typename IT, int MODE>
-__global__ __launch_bounds__(128, FS_UPDATE_WAVES) void fs_update_kernel(const FsParams P, int rows, uint8_t* __restrict__ state) {
+__global__ __launch_bounds__(128, FS_UPDATE_WAVES) void fs_update_kernel(const FsParams P, int rows, uint8_t* __restrict__ state,
+                                                                         const FsDest D) {
   extern __shared__ __align__(16) unsigned char fs_update_lds[];
   constexpr unsigned kNone = (IT)~(IT)0;
   const int tid = threadIdx.x;
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + tid;
   if (p >= P.M) return;
   if (MODE == FS_APPLY && state[p] != 1) return;
+  // q: the particle whose step is meant -- this one, or (FS_COPY) the ancestor of position p.  When the 64 positions
+  // of a tile have one ancestor, the tile keeps one copy and its 64 lanes share the work: lane 0 files the picks, then
+  // every lane takes a feature.
+  int64_t q = p;
+  bool one_ancestor = false;
+  if constexpr (MODE == FS_COPY) {
+    q = D.idx[p];
+    const int64_t q0 = __shfl(q, 0);
+    one_ancestor = (__ballot(1) == ~0ull) && (__ballot(q != q0) == 0ull);
+  }
+  const bool worker = !one_ancestor || (tid & 63) == 0;
+  int kept = 0;            // slots written so far: survivors close ranks as the pass goes
+  int32_t new_id = 0;
+  const int64_t pm = q, pf = slot_owner(P.shared_tile, q);
   const int nv = P.L, nblk = (nv + 63) >> 6;
   unsigned long long* const s_birth = reinterpret_cast<unsigned long long*>(fs_update_lds);   // [nblk][128]
   IT* const s_inv = reinterpret_cast<IT*>(s_birth + (size_t)nblk * 128);                     // [rows][128]
   IT* const s_next = s_inv + (size_t)rows * 128;                                              // [nv][128]
-  const double x = P.x[p], y = P.y[p], th = P.th[p];
-  const int n_old = min(P.nfeat[p], rows);
+  const double x = P.x[q], y = P.y[q], th = P.th[q];
+  const int n_old = min(P.nfeat[q], rows);
+  if (worker) {
   for (int j = 0; j < n_old; ++j) s_inv[j * 128 + tid] = (IT)kNone;
   // the association, inverted: sixteen picks are read together, then filed -- last measurement first, so that a
   // slot ends up with its first picker and every picker points to the next one of the same feature
@@ -491,7 +525,76 @@ __global__ __launch_bounds__(128, FS_UPDATE_WAVES) void fs_update_kernel(const F
     }
     s_birth[blk * 128 + tid] = birth;
   }
+  }  // worker: the picks are filed
   bool slid = false;       // the previous feature was discarded, this one takes its place unvisited
+  if (MODE == FS_COPY && one_ancestor) {
+    // ---- one ancestor for the whole tile: lane l works on features l, l + 64, ... and on the l-th birth; what the
+    // pass over the list decides (:377-404 -- a discarded feature makes the pass skip its successor) is a short
+    // scalar loop over three wave masks; the one copy goes to lane 0's region of the destination tile
+    const int lane = tid & 63, col = tid & ~63;   // lane 0's column of the tables
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int64_t p0 = p & ~(int64_t)63;
+    new_id = P.new_id[q];
+    for (int j0 = 0; j0 < n_old; j0 += 64) {
+      const int j = j0 + lane;
+      const bool valid = j < n_old;
+      Slot cur{1.0, 0.0, M2{1.0, 0.0, 0.0, 1.0}, 0.0, 0, 0};
+      bool upd = false, in_range = false, dflag = false;
+      if (valid) {
+        cur = load_slot(FREC(j));
+        const unsigned e = s_inv[j * 128 + col];
+        upd = e != kNone;
+        if (upd) {
+          const double* m = MREC(e);
+          M2 H;
+          const Predicted pr = predict_feature(RawFeat{cur.m0, cur.m1, cur.C.a, cur.C.b, cur.C.c, cur.C.d}, x, y, th, P.qt_r, P.qt_phi, &H);
+          ekf_update(cur, pr, H, FLD(m, M_ZR), FLD(m, M_ZPHI), FLD(m, M_BW));
+          for (unsigned u2 = s_next[e * 128 + col]; u2 != kNone; u2 = s_next[u2 * 128 + col]) {
+            const double* m2 = MREC(u2);
+            ekf_update(cur, pr, H, FLD(m2, M_ZR), FLD(m2, M_ZPHI), FLD(m2, M_BW));
+          }
+        } else {
+          const double dx = cur.m0 - x, dy = cur.m1 - y;
+          in_range = dx * dx + dy * dy <= P.r_max2;
+          dflag = in_range && (cur.cnt - 1 < 0);      // discarded if the pass visits it
+        }
+      }
+      const unsigned long long umask = __ballot(upd), dmask = __ballot(dflag);
+      const int n_here = min(n_old - j0, 64);
+      unsigned long long visited = 0, discard = 0;
+      for (int b = 0; b < n_here; ++b) {
+        if (slid) { slid = false; continue; }
+        visited |= 1ull << b;
+        if (!((umask >> b) & 1) && ((dmask >> b) & 1)) { discard |= 1ull << b; slid = true; }
+      }
+      if (valid && !upd && ((visited >> lane) & 1)) {
+        cur.w = P.p0;
+        if (in_range) cur.cnt = cur.cnt - 1;
+      }
+      const bool keep = valid && !((discard >> lane) & 1);
+      const unsigned long long kmask = __ballot(keep);
+      if (keep) store_slot(D.feat + tile_word(p0, P.F, kept + __popcll(kmask & ((1ull << lane) - 1ull)), F_WORDS), cur);
+      kept += __popcll(kmask);
+    }
+    int rank0 = 0;           // births before this block of measurements
+    for (int blk = 0; blk < nblk; ++blk) {
+      const unsigned long long births = s_birth[blk * 128 + col];
+      const int nb = __popcll(births);
+      const int r = rank0 + lane;
+      if (lane < nb && n_old + r < P.F) {          // (more than the capacity: reported by the weighing sweep)
+        unsigned long long mk = births;
+        for (int k = 0; k < lane; ++k) mk &= mk - 1;
+        const int u = (blk << 6) + __ffsll((long long)mk) - 1;
+        const double* m = MREC(u);
+        create_feature(D.feat + tile_word(p0, P.F, kept + r, F_WORDS), new_id + r, FLD(m, M_ZR), FLD(m, M_ZPHI), x, y, th, P.qt_r, P.qt_phi, P.p0);
+      }
+      rank0 += nb;
+    }
+    const int created = max(0, min(rank0, P.F - n_old));
+    kept += created;
+    new_id += created;
+  } else if (worker) {
   if constexpr (MODE == FS_WEIGH) {
     double wgt = 1.0;
     int n_assoc = 0;
@@ -539,8 +642,10 @@ __global__ __launch_bounds__(128, FS_UPDATE_WAVES) void fs_update_kernel(const F
     if (n_assoc == 0) wgt = P.p0;
     P.wout[p] = wgt;
   } else {
-    int32_t new_id = P.new_id[p];
-    int kept = 0;            // slots written so far: survivors close ranks as the pass goes
+    // FS_APPLY writes the particle's own region in place (the host has made every tile private before);
+    // FS_COPY writes position p's region of the other buffer
+    double* const out = MODE == FS_COPY ? D.feat : P.feat;
+    new_id = P.new_id[q];
     // slot j + 1 and the measurement that picked it are on their way while slot j is worked on (two ahead: no gain)
     struct Ahead { Slot sl; unsigned e; double zr, zp, bw; };
     auto fetch = [&](int jj) {
@@ -584,8 +689,8 @@ __global__ __launch_bounds__(128, FS_UPDATE_WAVES) void fs_update_kernel(const F
         }
       }
       if (keep) {
-        double* g = FREC(kept);
-        if (upd || kept != j) {
+        double* g = out + tile_word(p, P.F, kept, F_WORDS);
+        if (MODE == FS_COPY || upd || kept != j) {
           store_slot(g, cur);
         } else if (touched) {                    // only the weight / counter pair changed
           FLD(g, F_W) = cur.w;
@@ -603,15 +708,36 @@ __global__ __launch_bounds__(128, FS_UPDATE_WAVES) void fs_update_kernel(const F
         births &= births - 1;
         if (n_list >= P.F) continue;             // reported by the weighing sweep
         const double* m = MREC(u);
-        create_feature(FREC(kept), new_id++, FLD(m, M_ZR), FLD(m, M_ZPHI), x, y, th, P.qt_r, P.qt_phi, P.p0);
+        create_feature(out + tile_word(p, P.F, kept, F_WORDS), new_id++, FLD(m, M_ZR), FLD(m, M_ZPHI), x, y, th, P.qt_r, P.qt_phi, P.p0);
         ++n_list;
         ++kept;
       }
     }
+  }
+  }  // one particle's sweep
+  if constexpr (MODE == FS_APPLY) {
     P.nfeat[p] = kept;
     P.new_id[p] = new_id;
     state[p] = 2;            // applied: a second request for this particle in the same step finds nothing to do
   }
+  if constexpr (MODE == FS_COPY) {
+    D.nfeat[p] = kept;
+    D.new_id[p] = new_id;
+    if ((tid & 63) == 0) D.shared_tile[p >> 6] = one_ancestor ? 1 : 0;
+  }
+}
+
+// every particle of a shared tile gets its own copy of the tile's slots (block row y = slot); the caller then clears the
+// tile flags.  For the paths that address a particle's own region: in-place updates, row packing, state read-out.
+__global__ void fs_unshare_kernel(const uint8_t* __restrict__ shared_tile, int64_t M, int F, const int32_t* __restrict__ nfeat,
+                                  double* __restrict__ feat) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int slot = blockIdx.y;
+  if (p >= M || (p & 63) == 0 || !shared_tile[p >> 6] || slot >= nfeat[p]) return;
+  const double* a = feat + tile_word(p & ~(int64_t)63, F, slot, F_WORDS);
+  double* b = feat + tile_word(p, F, slot, F_WORDS);
+#pragma unroll
+  for (int w = 0; w < F_WORDS; ++w) FLD(b, w) = FLD(a, w);
 }
 
 // marks the particles of a list (ancestor indices, selected rows) whose update has not been applied yet
@@ -640,23 +766,6 @@ __global__ void fs_max_sel_kernel(const int64_t* __restrict__ sel, int64_t n, co
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) v = max(v, nfeat[sel[j]]);
   for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
   if ((threadIdx.x & 63) == 0) atomicMax(out, v);
-}
-
-// feature slots of the drawn ancestors: block row y = slot
-__global__ void fs_gather_kernel(const int64_t* __restrict__ idx, int64_t M, int F, const int32_t* __restrict__ nfeat_in,
-                                 const int32_t* __restrict__ newid_in, int32_t* __restrict__ nfeat_out,
-                                 int32_t* __restrict__ newid_out, const double* __restrict__ in, double* __restrict__ out) {
-  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int slot = blockIdx.y;
-  if (p >= M) return;
-  const int64_t src = idx[p];
-  const int n = nfeat_in[src];
-  if (slot == 0) { nfeat_out[p] = n; newid_out[p] = newid_in[src]; }
-  if (slot >= n) return;
-  const double* a = in + tile_word(src, F, slot, F_WORDS);
-  double* b = out + tile_word(p, F, slot, F_WORDS);
-#pragma unroll
-  for (int w = 0; w < F_WORDS; ++w) FLD(b, w) = FLD(a, w);
 }
 
 __global__ void fs_total_kernel(const double* __restrict__ cdf, int64_t n, double floor_value, double* __restrict__ scal) {
@@ -748,7 +857,9 @@ struct FsState {
   int F = 0;
   int64_t M = 0, tiles = 0;
   int cur = 0;
-  double* feat[2] = {nullptr, nullptr};   // feature slots, double-buffered for the gather
+  double* feat[2] = {nullptr, nullptr};   // feature slots, double-buffered for the resampling
+  uint8_t* shared[2] = {nullptr, nullptr};  // per tile of feat[b]: its 64 particles share the copy in lane 0's region
+  bool maybe_shared = false;              // some tile of the current buffer may be shared (set by a resampling, cleared by fs_make_private)
   int32_t* nfeat[2] = {nullptr, nullptr};
   int32_t* newid[2] = {nullptr, nullptr};
   double* meas = nullptr; int mcap = 0;   // per-step measurements, mcap rows per tile
@@ -771,7 +882,7 @@ struct FsState {
 static void fs_free(FsState* s) {
   if (!s) return;
   void* all[] = {s->feat[0], s->feat[1], s->nfeat[0], s->nfeat[1], s->newid[0], s->newid[1], s->meas, s->d_truth, s->d_sectors,
-                 s->overflow, s->d_maxfeat, s->d_ints, s->d_normals, s->stage, s->state};
+                 s->overflow, s->d_maxfeat, s->d_ints, s->d_normals, s->stage, s->state, s->shared[0], s->shared[1]};
   for (void* q : all) if (q) (void)hipFree(q);
   delete s;
 }
@@ -806,24 +917,39 @@ static int fs_count_features(mclhip_ctx* c, FsState* s, const int32_t* nfeat) {
 
 // one launch of the feature sweep of the open step: FS_WEIGH for every particle, FS_APPLY for those marked in s->state
 template <typename IT>
-static int fs_launch_sweep_typed(mclhip_ctx* c, FsState* s, int mode) {
+static int fs_launch_sweep_typed(mclhip_ctx* c, FsState* s, int mode, const FsDest& dest) {
   const dim3 grid((unsigned)((s->M + 127) / 128));
   auto* const weigh = fs_update_kernel<IT, FS_WEIGH>;
   auto* const apply = fs_update_kernel<IT, FS_APPLY>;
-  auto* const k = mode == FS_WEIGH ? weigh : apply;
+  auto* const copy = fs_update_kernel<IT, FS_COPY>;
+  auto* const k = mode == FS_WEIGH ? weigh : (mode == FS_APPLY ? apply : copy);
   if (s->step_lds > 48 * 1024)
     F_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->step_lds));
-  hipLaunchKernelGGL(k, grid, dim3(128), s->step_lds, c->stream, s->step_params, s->step_rows, s->state);
+  hipLaunchKernelGGL(k, grid, dim3(128), s->step_lds, c->stream, s->step_params, s->step_rows, s->state, dest);
   F_HIP(hipGetLastError());
   return MCLHIP_OK;
 }
-static int fs_launch_sweep(mclhip_ctx* c, FsState* s, int mode) {
-  return s->step_entry == 1 ? fs_launch_sweep_typed<unsigned char>(c, s, mode) : fs_launch_sweep_typed<unsigned short>(c, s, mode);
+static int fs_launch_sweep(mclhip_ctx* c, FsState* s, int mode, const FsDest& dest = FsDest{nullptr, nullptr, nullptr, nullptr, nullptr}) {
+  return s->step_entry == 1 ? fs_launch_sweep_typed<unsigned char>(c, s, mode, dest) : fs_launch_sweep_typed<unsigned short>(c, s, mode, dest);
+}
+
+// gives every particle of the current buffer its own copy of its slots (tiles whose particles descend from one ancestor
+// keep a single copy after a resampling): needed before anything addresses a particle's own region
+static int fs_make_private(mclhip_ctx* c, FsState* s) {
+  if (!s->maybe_shared) return MCLHIP_OK;
+  const int a = s->cur;
+  hipLaunchKernelGGL(fs_unshare_kernel, dim3((unsigned)((s->M + 255) / 256), s->F), dim3(256), 0, c->stream,
+                     (const uint8_t*)s->shared[a], s->M, s->F, (const int32_t*)s->nfeat[a], s->feat[a]);
+  F_HIP(hipGetLastError());
+  F_HIP(hipMemsetAsync(s->shared[a], 0, (size_t)s->tiles, c->stream));
+  s->maybe_shared = false;
+  return MCLHIP_OK;
 }
 
 // applies the open step's updates to the particles of a list (device pointer to n indices) that have not had them yet
 static int fs_apply_list(mclhip_ctx* c, FsState* s, const int64_t* d_list, int64_t n) {
   if (!s->step_open || n <= 0) return MCLHIP_OK;
+  F_TRY(fs_make_private(c, s));
   hipLaunchKernelGGL(fs_mark_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_list, n, s->M, s->state);
   F_HIP(hipGetLastError());
   return fs_launch_sweep(c, s, FS_APPLY);
@@ -917,7 +1043,7 @@ static int fs_enqueue_kernel(mclhip_ctx* c, double v, double omega, double dt, c
   P.index0 = c->first_index;
   P.x = (double*)c->px[c->cur]; P.y = (double*)c->py[c->cur]; P.th = (double*)c->pth[c->cur]; P.wout = c->w[c->cur];
   P.nfeat = s->nfeat[a]; P.new_id = s->newid[a];
-  P.feat = s->feat[a]; P.meas = s->meas;
+  P.feat = s->feat[a]; P.meas = s->meas; P.shared_tile = s->shared[a];
   P.overflow = s->overflow;
   P.sectors = s->d_sectors;
   P.far_r = 0.0;
@@ -969,6 +1095,8 @@ int mclhip_fs_init(mclhip_ctx* c, int64_t M, int capacity) {
     F_HIP(hipMalloc((void**)&s->newid[b], M * sizeof(int32_t)));
     F_HIP(hipMemset(s->nfeat[b], 0, M * sizeof(int32_t)));
     F_HIP(hipMemset(s->newid[b], 0, M * sizeof(int32_t)));
+    F_HIP(hipMalloc((void**)&s->shared[b], (size_t)s->tiles));
+    F_HIP(hipMemset(s->shared[b], 0, (size_t)s->tiles));
   }
   F_HIP(hipMalloc((void**)&s->overflow, sizeof(int32_t)));
   F_HIP(hipMemset(s->overflow, 0, sizeof(int32_t)));
@@ -990,19 +1118,18 @@ int mclhip_fs_step(mclhip_ctx* c, double v, double omega, double dt, const doubl
   F_TRY(fs_enqueue_kernel(c, v, omega, dt, alpha, truth_r, truth_phi, truth_valid, L, ints, normals, seed));
   FsState* s = (FsState*)c->fs;
   const int64_t M = s->M;
-  const int a = s->cur, b = 1 - s->cur;
+  const int b = 1 - s->cur;
   // normalise by the Python-order sum with its 1e-8 floor, then the guarded low-variance walk (:411-431)
   F_TRY(launch_sequential_total(c));                     // c->cdf_exact[M-1] = sum_w, added one by one
   const unsigned g = (unsigned)((M + 255) / 256);
   hipLaunchKernelGGL(fs_total_kernel, dim3(1), dim3(64), 0, c->stream, c->cdf_exact, M, 1e-8, c->scal);
   hipLaunchKernelGGL(fs_divide_kernel, dim3(g), dim3(256), 0, c->stream, c->w[c->cur], M, c->scal);
   F_TRY(launch_resample(c, r, MCLHIP_RESAMPLE_PARALLEL)); // flips c->cur; c->idx = ancestors
-  // updates, births and decay of the particles that have descendants; then the feature slots follow their ancestors
-  F_TRY(fs_apply_list(c, s, c->idx, M));
+  // updates, births and decay of the drawn ancestors, written straight into their descendants' places: one sweep per
+  // position, or one per tile where the whole tile has one ancestor
+  F_TRY(fs_launch_sweep(c, s, FS_COPY, FsDest{c->idx, s->feat[b], s->nfeat[b], s->newid[b], s->shared[b]}));
   s->step_open = false;
-  hipLaunchKernelGGL(fs_gather_kernel, dim3(g, s->F), dim3(256), 0, c->stream, c->idx, M, s->F, s->nfeat[a], s->newid[a],
-                     s->nfeat[b], s->newid[b], (const double*)s->feat[a], s->feat[b]);
-  F_HIP(hipGetLastError());
+  s->maybe_shared = true;
   s->cur = b;
   F_TRY(fs_count_features(c, s, s->nfeat[b]));
   int32_t ov = 0;
@@ -1021,6 +1148,7 @@ int mclhip_fs_get_state(mclhip_ctx* c, double* pose, double* w, int32_t* nfeat, 
   FsState* s = (FsState*)c->fs;
   const int64_t M = s->M;
   const int F = s->F, a = s->cur;
+  F_TRY(fs_make_private(c, s));
   if (s->step_open) {                            // between the per-particle kernels and the exchange: every particle's update
     hipLaunchKernelGGL(fs_mark_range_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, c->stream, (int64_t)0, M, s->state);
     F_HIP(hipGetLastError());
@@ -1116,6 +1244,7 @@ int mclhip_fs_shard_pack(mclhip_ctx* c, const int64_t* lo, const int64_t* hi, in
   if (total == 0) return MCLHIP_OK;
   if (!rows) return fail(c, MCLHIP_E_ARG, "rows is NULL");
   F_TRY(fs_stage(c, s, total * words));
+  F_TRY(fs_make_private(c, s));
   if (s->step_open) {                           // rows travel with their step's updates applied
     for (int k = 0; k < nslices; ++k)
       if (hi[k] > lo[k])
@@ -1175,6 +1304,7 @@ int mclhip_fs_shard_pack_drawn(mclhip_ctx* c, void* rows) {
   if (!rows) return fail(c, MCLHIP_E_ARG, "rows is NULL");
   if (!c->sel || c->sel_cap < total) return fail(c, MCLHIP_E_STATE, "call mclhip_shard_pack_drawn first (it selects the rows)");
   F_TRY(fs_stage(c, s, total * words));
+  F_TRY(fs_make_private(c, s));
   F_TRY(fs_apply_list(c, s, (const int64_t*)c->sel, total));
   hipLaunchKernelGGL(fs_pack_sel_kernel, dim3((unsigned)((total + 63) / 64), s->row_slots + 1), dim3(64), 0, c->stream,
                      (const int64_t*)c->sel, total, s->F, s->row_slots, s->nfeat[s->cur], s->newid[s->cur],
@@ -1201,6 +1331,7 @@ int mclhip_fs_shard_unpack(mclhip_ctx* c, const void* rows, int64_t L) {
   F_TRY(fs_stage(c, s, L * words));
   F_HIP(hipMemcpyAsync(s->stage, rows, (size_t)L * words * 8, hipMemcpyDefault, c->stream));
   const int b = 1 - s->cur;
+  F_HIP(hipMemsetAsync(s->shared[b], 0, (size_t)s->tiles, c->stream));   // every particle gets its own slots from its row
   // the received row every local position took was left in c->kscan by mclhip_shard_unpack_drawn
   hipLaunchKernelGGL(fs_unpack_rows_kernel, dim3((unsigned)((s->M + 63) / 64), s->row_slots + 1), dim3(64), 0, c->stream,
                      reinterpret_cast<const int64_t*>(c->kscan), (int64_t)0, L, s->M, s->F, s->row_slots,
@@ -1210,6 +1341,7 @@ int mclhip_fs_shard_unpack(mclhip_ctx* c, const void* rows, int64_t L) {
   F_HIP(hipStreamSynchronize(c->stream));
   s->cur = b;
   s->step_open = false;
+  s->maybe_shared = false;
   return MCLHIP_OK;
 }
 

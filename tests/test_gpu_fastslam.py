@@ -175,8 +175,11 @@ def test_dense_landmark_field_against_the_oracle():
     lm = np.stack([rng.uniform(-8, 33, nl), rng.uniform(-24, 8, nl), np.zeros(nl)], 1).astype(np.float32)
     ctx = L.Context(0, L.F64)
     ctx.fs_init(M, cap)
+    ctx2 = L.Context(0, L.F64)
+    ctx2.fs_init(M, cap)
     orc = F.OracleFastSLAM(M, lm)
     x_gt = [0, 0, 0]
+    one_ancestor_tiles = mixed_tiles = 0
     for t in range(7):
         ut = [25, 0.001] if t % 5 else [25, -np.pi / 2 * 5]
         x_gt = F.true_pose_step(x_gt, ut)
@@ -186,10 +189,19 @@ def test_dense_landmark_field_against_the_oracle():
         normals = rng.randn(M, 2 * nv)
         ru = float(rng.rand())
         idx = ctx.fs_step(ut[0], ut[1], F.DT, F.ALPHA, tr, tp, tv, ints, normals, ru / M, want_idx=True)
+        idx2 = ctx2.fs_step(ut[0], ut[1], F.DT, F.ALPHA, tr, tp, tv, ints, normals, ru / M, want_idx=True)
         orc.step(ut, ints, normals, ru)
-        assert np.array_equal(idx, orc.last_idx), t
+        assert np.array_equal(idx, orc.last_idx) and np.array_equal(idx2, orc.last_idx), t
         _compare(ctx.fs_get_state(), orc.state(cap), t)
+        one_ancestor_tiles += sum(int(len(set(idx[k:k + 64].tolist())) == 1) for k in (0, 64))
+        mixed_tiles += sum(int(len(set(idx[k:k + 64].tolist())) > 1) for k in (0, 64))
     assert nv > 40 and int(ctx.fs_get_state()["nfeat"].max()) > nv
+    # with this many landmarks the weights are peaked: whole tiles of 64 particles descend from one ancestor and keep
+    # one copy of its feature slots.  ctx read its state after every step (which gives every particle its own copy
+    # again); ctx2 ran all steps on the shared copies and is read only now
+    assert one_ancestor_tiles >= 4 and mixed_tiles >= 1, (one_ancestor_tiles, mixed_tiles)
+    _compare(ctx2.fs_get_state(), orc.state(cap), 99)
+    ctx2.close()
 
 
 def test_device_measurement_noise_is_standard_normal():
