@@ -430,6 +430,39 @@ int mclhip_fs_shard_pack_drawn(mclhip_ctx* ctx, void* rows);
  * ancestor from the L received rows (the row that call chose for it). */
 int mclhip_fs_shard_unpack(mclhip_ctx* ctx, const void* rows, int64_t L);
 
+/* The same step with the host out of the loop (no counterpart in the reference): every call only
+ * enqueues on the context's stream (mclhip_set_stream) and exchanges data through DEVICE pointers
+ * that RCCL collectives read and write; one device-to-host read per step (row counts, longest
+ * feature list, overflow flags: all in one gathered block).  Order of a step:
+ *   mclhip_fs_dshard_kernel           per-particle kernels; chunk sums of the raw weights -> d_chunks_out
+ *   [all-gather chunks]
+ *   mclhip_fs_dshard_scan(lasts NULL) local scan of the raw weights; header + records -> d_records_out
+ *   [all-gather records]
+ *   mclhip_fs_dshard_finalize_raw     exact running sums of the raw weights; (last sum, overflow flag) -> d_last_out[2]
+ *   [all-gather lasts]                the last rank's last sum is sum_w of fast_slam1.py:411-413
+ *   mclhip_fs_dshard_scan(lasts)      w /= max(1e-8, sum_w) (:415-418), local scan of the normalised weights
+ *   [all-gather records]
+ *   mclhip_dshard_finalize            running sums c_i (:421-428), which rows are drawn -> d_counts_out[world + 1]
+ *   mclhip_fs_dshard_select           pose rows of the drawn particles -> d_rows (room for M_local + world rows of six
+ *                                     doubles); the step's updates (:318-404) for exactly those; d_info_out[3] =
+ *                                     longest feature list among them, capacity overflow, record overflow of round one
+ *   [all-gather counts + info, read on the host; mclhip_fs_set_row_slots(longest list over all ranks)]
+ *   mclhip_fs_dshard_pack             feature rows of the selected particles -> d_feature_rows
+ *   [all-to-all of the pose rows, all-to-all of the feature rows]
+ *   mclhip_fs_dshard_unpack           the local set from the received rows (max_features: the agreed longest list) */
+int mclhip_fs_dshard_kernel(mclhip_ctx* ctx, double v, double omega, double dt, const double alpha[6],
+                            const double* truth_r, const double* truth_phi, const uint8_t* truth_valid, int L,
+                            const int16_t* ints, const double* normals, uint64_t seed, double* d_chunks_out);
+int mclhip_fs_dshard_scan(mclhip_ctx* ctx, const double* d_all_chunks, const double* d_all_lasts, const int64_t* firsts,
+                          int world, int rank, void* d_records_out, int cap);
+int mclhip_fs_dshard_finalize_raw(mclhip_ctx* ctx, const void* d_all_records, const int64_t* firsts, int world, int rank,
+                                  int cap, double* d_last_out);
+int mclhip_fs_dshard_select(mclhip_ctx* ctx, int world, const int64_t* d_counts, const double* d_first_round, void* d_rows,
+                            int64_t* d_info_out);
+int mclhip_fs_dshard_pack(mclhip_ctx* ctx, int64_t n_rows, void* d_feature_rows);
+int mclhip_fs_dshard_unpack(mclhip_ctx* ctx, const void* d_rows, const void* d_feature_rows, int64_t L, double r,
+                            int max_features);
+
 /* Measurement ------------------------------------------------------------ */
 
 /* Per-kernel timing with HIP events on the context's own stream.

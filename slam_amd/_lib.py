@@ -106,6 +106,13 @@ PROTOTYPES = {
     "mclhip_fs_set_row_slots": (C.c_int, [_ctx_p, C.c_int]),
     "mclhip_fs_shard_pack": (C.c_int, [_ctx_p, _i64_p, _i64_p, C.c_int, C.c_void_p]),
     "mclhip_fs_shard_apply_drawn": (C.c_int, [_ctx_p, C.POINTER(C.c_int32)]),
+    "mclhip_fs_dshard_kernel": (C.c_int, [_ctx_p, C.c_double, C.c_double, C.c_double, _dbl_p, _dbl_p, _dbl_p, _u8_p,
+                                          C.c_int, _i16_p, _dbl_p, C.c_uint64, C.c_void_p]),
+    "mclhip_fs_dshard_scan": (C.c_int, [_ctx_p, C.c_void_p, C.c_void_p, _i64_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "mclhip_fs_dshard_finalize_raw": (C.c_int, [_ctx_p, C.c_void_p, _i64_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mclhip_fs_dshard_select": (C.c_int, [_ctx_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mclhip_fs_dshard_pack": (C.c_int, [_ctx_p, C.c_int64, C.c_void_p]),
+    "mclhip_fs_dshard_unpack": (C.c_int, [_ctx_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_int]),
     "mclhip_fs_shard_pack_drawn": (C.c_int, [_ctx_p, C.c_void_p]),
     "mclhip_fs_shard_unpack": (C.c_int, [_ctx_p, C.c_void_p, C.c_int64]),
     "mclhip_shard_plan_drawn": (C.c_int, [_ctx_p, _i64_p, C.c_int, C.c_int, C.c_double, _i64_p]),
@@ -556,6 +563,45 @@ class Context:
         self._ck(self.lib.mclhip_fs_shard_kernel(self.h, float(v), float(omega), float(dt), _p(al, _dbl_p),
                                                  _p(tr_, _dbl_p), _p(tp, _dbl_p), _p(tv, _u8_p), len(tr_),
                                                  _p(ints, _i16_p), _p(normals, _dbl_p), int(seed)), "mclhip_fs_shard_kernel")
+
+    def fs_dshard_kernel(self, v, omega, dt, alpha, truth_r, truth_phi, truth_valid, ints, normals, seed, d_chunks):
+        """The per-particle kernels of one step, enqueued only; chunk sums of the raw weights -> device pointer."""
+        al = _f64(alpha, (6,))
+        tr_, tp = _f64(truth_r), _f64(truth_phi)
+        tv = np.ascontiguousarray(truth_valid, dtype=np.uint8)
+        nv = int(np.count_nonzero(tv))
+        if ints is not None:
+            ints = np.ascontiguousarray(ints, dtype=np.int16)
+            if ints.shape != (self.fs_M, 3, 12):
+                raise ValueError("ints must have shape (M, 3, 12)")
+        if normals is not None:
+            normals = _f64(normals, (self.fs_M, 2 * nv))
+        self._fs_inputs = (ints, normals)         # read by copies that may still be in flight when this returns
+        self._ck(self.lib.mclhip_fs_dshard_kernel(self.h, float(v), float(omega), float(dt), _p(al, _dbl_p),
+                                                  _p(tr_, _dbl_p), _p(tp, _dbl_p), _p(tv, _u8_p), len(tr_),
+                                                  _p(ints, _i16_p), _p(normals, _dbl_p), int(seed), C.c_void_p(d_chunks)),
+                 "mclhip_fs_dshard_kernel")
+
+    def fs_dshard_scan(self, d_all_chunks, d_all_lasts, firsts, rank, d_records, cap):
+        f = np.ascontiguousarray(firsts, np.int64)
+        self._ck(self.lib.mclhip_fs_dshard_scan(self.h, C.c_void_p(d_all_chunks), C.c_void_p(d_all_lasts), _p(f, _i64_p),
+                                                len(f) - 1, int(rank), C.c_void_p(d_records), int(cap)), "mclhip_fs_dshard_scan")
+
+    def fs_dshard_finalize_raw(self, d_all_records, firsts, rank, cap, d_last):
+        f = np.ascontiguousarray(firsts, np.int64)
+        self._ck(self.lib.mclhip_fs_dshard_finalize_raw(self.h, C.c_void_p(d_all_records), _p(f, _i64_p), len(f) - 1, int(rank),
+                                                        int(cap), C.c_void_p(d_last)), "mclhip_fs_dshard_finalize_raw")
+
+    def fs_dshard_select(self, world, d_counts, d_first_round, d_rows, d_info):
+        self._ck(self.lib.mclhip_fs_dshard_select(self.h, int(world), C.c_void_p(d_counts), C.c_void_p(d_first_round),
+                                                  C.c_void_p(d_rows), C.c_void_p(d_info)), "mclhip_fs_dshard_select")
+
+    def fs_dshard_pack(self, n_rows, d_feature_rows):
+        self._ck(self.lib.mclhip_fs_dshard_pack(self.h, int(n_rows), C.c_void_p(d_feature_rows)), "mclhip_fs_dshard_pack")
+
+    def fs_dshard_unpack(self, d_rows, d_feature_rows, L, r, max_features):
+        self._ck(self.lib.mclhip_fs_dshard_unpack(self.h, C.c_void_p(d_rows), C.c_void_p(d_feature_rows), int(L), float(r),
+                                                  int(max_features)), "mclhip_fs_dshard_unpack")
 
     def fs_shard_last_sum(self):
         v = C.c_double(0.0)

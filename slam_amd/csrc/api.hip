@@ -1106,6 +1106,37 @@ int mclhip_dshard_finalize(mclhip_ctx* c, const void* d_all_records, const int64
   return MCLHIP_OK;
 }
 
+int mclhip_fs_dshard_scan(mclhip_ctx* c, const double* d_all_chunks, const double* d_all_lasts, const int64_t* firsts, int world,
+                          int rank, void* d_records_out, int cap) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, false, false, true));
+  if (!d_all_chunks || !d_records_out || cap < 1) return fail(c, MCLHIP_E_ARG, "device pointer NULL or cap < 1");
+  if (c->m_total <= 0) return fail(c, MCLHIP_E_STATE, "call mclhip_shard_set first");
+  ShardLayout lay;
+  MCL_TRY(make_layout(c, lay, firsts, world, rank));
+  MCL_TRY(launch_fs_dshard_scan(c, d_all_chunks, d_all_lasts, lay, d_records_out, cap));
+  return MCLHIP_OK;
+}
+
+int mclhip_fs_dshard_finalize_raw(mclhip_ctx* c, const void* d_all_records, const int64_t* firsts, int world, int rank, int cap,
+                                  double* d_last_out) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, false, false, true));
+  if (!d_all_records || !d_last_out || cap < 1) return fail(c, MCLHIP_E_ARG, "device pointer NULL or cap < 1");
+  ShardLayout lay;
+  MCL_TRY(make_layout(c, lay, firsts, world, rank));
+  const int64_t n_all = (int64_t)world * cap;
+  if (n_all > c->g_records_cap) {
+    MCL_HIP(c, hipStreamSynchronize(c->stream));
+    MCL_TRY(dev_alloc(c, &c->g_records, (size_t)n_all * irr_record_bytes()));
+    MCL_TRY(dev_alloc(c, &c->g_bases, (size_t)n_all * run_base_bytes()));
+    c->g_records_cap = n_all;
+  }
+  if (!c->small_i) MCL_TRY(dev_alloc(c, &c->small_i, 1024 * sizeof(int64_t)));
+  MCL_TRY(launch_fs_dshard_finalize_raw(c, d_all_records, lay, cap, d_last_out));
+  return MCLHIP_OK;
+}
+
 int mclhip_dshard_pack(mclhip_ctx* c, int world, void* d_rows) {
   MCL_TRY(use(c));
   MCL_TRY(need(c, false, false, true));

@@ -1321,6 +1321,123 @@ int mclhip_fs_shard_pack_drawn(mclhip_ctx* c, void* rows) {
   return MCLHIP_OK;
 }
 
+}  // extern "C"
+
+/* ---- the same over several GPUs without the host in the loop: every call below only enqueues ---- */
+
+// marks the first n = counts[0] + ... + counts[world - 1] particles of a list, n on the device
+__global__ void fs_mark_counted_kernel(const int64_t* __restrict__ list, const int64_t* __restrict__ counts, int world, int64_t M,
+                                       uint8_t* __restrict__ state) {
+  int64_t n = 0;
+  for (int d = 0; d < world; ++d) n += counts[d];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t p = list[i];
+  if (p >= 0 && p < M && state[p] == 0) state[p] = 1;
+}
+
+// info[0] = largest feature count among the listed particles, info[1] = a particle ran out of slots,
+// info[2] = the first record exchange overflowed
+__global__ void fs_select_info_kernel(const int64_t* __restrict__ list, const int64_t* __restrict__ counts, int world,
+                                      const int32_t* __restrict__ nfeat, const int32_t* __restrict__ overflow,
+                                      const double* __restrict__ first_round, int64_t* __restrict__ info) {
+  __shared__ int s_max[256];
+  int64_t n = 0;
+  for (int d = 0; d < world; ++d) n += counts[d];
+  int v = 0;
+  for (int64_t j = threadIdx.x; j < n; j += blockDim.x) v = max(v, nfeat[list[j]]);
+  s_max[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) s_max[threadIdx.x] = max(s_max[threadIdx.x], s_max[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { info[0] = s_max[0]; info[1] = *overflow ? 1 : 0; info[2] = first_round[1] != 0.0 ? 1 : 0; }
+}
+
+extern "C" {
+
+int mclhip_fs_dshard_kernel(mclhip_ctx* c, double v, double omega, double dt, const double alpha[6], const double* truth_r,
+                            const double* truth_phi, const uint8_t* truth_valid, int L, const int16_t* ints,
+                            const double* normals, uint64_t seed, double* d_chunks_out) {
+  if (!c || !d_chunks_out) return MCLHIP_E_ARG;
+  F_TRY(fs_enqueue_kernel(c, v, omega, dt, alpha, truth_r, truth_phi, truth_valid, L, ints, normals, seed));
+  F_TRY(launch_shard_weights(c, MCLHIP_W_PRODUCT, 0.0));      // chunk sums of the raw weights: they only place the scans
+  const int64_t nch = (c->M + kSumChunk - 1) / kSumChunk;
+  F_HIP(hipMemcpyAsync(d_chunks_out, c->chunk_sums, nch * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  return MCLHIP_OK;
+}
+
+int mclhip_fs_dshard_select(mclhip_ctx* c, int world, const int64_t* d_counts, const double* d_first_round, void* d_rows,
+                            int64_t* d_info_out) {
+  if (!c) return MCLHIP_E_ARG;
+  F_HIP(hipSetDevice(c->device));
+  if (!c->fs) return fail(c, MCLHIP_E_STATE, "call mclhip_fs_init first");
+  if (!d_counts || !d_first_round || !d_rows || !d_info_out || world < 1 || world > 64)
+    return fail(c, MCLHIP_E_ARG, "device pointer NULL or world outside 1..64");
+  FsState* s = (FsState*)c->fs;
+  const int64_t most = s->M + world;             // every local row once, the rows at the rank boundaries twice
+  if (c->sel_cap < most) {
+    F_HIP(hipStreamSynchronize(c->stream));
+    if (c->sel) (void)hipFree(c->sel);
+    c->sel = nullptr; c->sel_cap = 0;
+    F_HIP(hipMalloc((void**)&c->sel, (size_t)most * sizeof(int64_t)));
+    c->sel_cap = most;
+  }
+  F_TRY(launch_pack_drawn(c, world, (double*)d_rows, (int64_t*)c->sel));
+  if (s->step_open) {
+    F_TRY(fs_make_private(c, s));
+    hipLaunchKernelGGL(fs_mark_counted_kernel, dim3((unsigned)((most + 255) / 256)), dim3(256), 0, c->stream,
+                       (const int64_t*)c->sel, d_counts, world, s->M, s->state);
+    F_HIP(hipGetLastError());
+    F_TRY(fs_launch_sweep(c, s, FS_APPLY));
+  }
+  hipLaunchKernelGGL(fs_select_info_kernel, dim3(1), dim3(256), 0, c->stream, (const int64_t*)c->sel, d_counts, world,
+                     (const int32_t*)s->nfeat[s->cur], (const int32_t*)s->overflow, d_first_round, d_info_out);
+  F_HIP(hipGetLastError());
+  return MCLHIP_OK;
+}
+
+int mclhip_fs_dshard_pack(mclhip_ctx* c, int64_t n_rows, void* d_feature_rows) {
+  if (!c) return MCLHIP_E_ARG;
+  F_HIP(hipSetDevice(c->device));
+  if (!c->fs) return fail(c, MCLHIP_E_STATE, "call mclhip_fs_init first");
+  FsState* s = (FsState*)c->fs;
+  if (n_rows == 0) return MCLHIP_OK;
+  if (!d_feature_rows || n_rows < 0 || n_rows > c->sel_cap) return fail(c, MCLHIP_E_ARG, "rows NULL or more rows than were selected");
+  hipLaunchKernelGGL(fs_pack_sel_kernel, dim3((unsigned)((n_rows + 63) / 64), s->row_slots + 1), dim3(64), 0, c->stream,
+                     (const int64_t*)c->sel, n_rows, s->F, s->row_slots, s->nfeat[s->cur], s->newid[s->cur],
+                     (const double*)s->feat[s->cur], (unsigned long long*)d_feature_rows, s->overflow);
+  F_HIP(hipGetLastError());
+  return MCLHIP_OK;
+}
+
+int mclhip_fs_dshard_unpack(mclhip_ctx* c, const void* d_rows, const void* d_feature_rows, int64_t L, double r, int max_features) {
+  if (!c) return MCLHIP_E_ARG;
+  F_HIP(hipSetDevice(c->device));
+  if (!c->fs) return fail(c, MCLHIP_E_STATE, "call mclhip_fs_init first");
+  if (!d_rows || !d_feature_rows || L <= 0) return fail(c, MCLHIP_E_ARG, "rows NULL or empty");
+  FsState* s = (FsState*)c->fs;
+  F_TRY(launch_unpack_drawn(c, (const double*)d_rows, L, r, true));   // poses and weights; the row every position took -> c->kscan
+  const int b = 1 - s->cur;
+  F_HIP(hipMemsetAsync(s->shared[b], 0, (size_t)s->tiles, c->stream));
+  hipLaunchKernelGGL(fs_unpack_rows_kernel, dim3((unsigned)((s->M + 63) / 64), s->row_slots + 1), dim3(64), 0, c->stream,
+                     reinterpret_cast<const int64_t*>(c->kscan), (int64_t)0, L, s->M, s->F, s->row_slots,
+                     (const unsigned long long*)d_feature_rows, s->nfeat[b], s->newid[b], s->feat[b]);
+  F_HIP(hipGetLastError());
+  s->cur = b;
+  s->step_open = false;
+  s->maybe_shared = false;
+  // no particle of any rank holds more features than the longest list that travelled: the next step's tables are sized by it
+  s->max_feat = max_features;
+  s->max_feat_valid = true;
+  return MCLHIP_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
+
 int mclhip_fs_shard_unpack(mclhip_ctx* c, const void* rows, int64_t L) {
   if (!c) return MCLHIP_E_ARG;
   F_HIP(hipSetDevice(c->device));

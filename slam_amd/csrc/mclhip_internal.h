@@ -268,6 +268,9 @@ struct ShardLayout {   // who holds what of the global particle vector (at most 
 };
 int launch_dshard_scan(mclhip_ctx* c, const double* d_all_chunks, const ShardLayout& lay, void* d_rec_out, int cap);
 int launch_dshard_finalize(mclhip_ctx* c, const void* d_all_rec, const ShardLayout& lay, int cap, double r, int64_t* d_counts);
+int launch_fs_dshard_scan(mclhip_ctx* c, const double* d_all_chunks, const double* d_lasts, const ShardLayout& lay,
+                          void* d_rec_out, int cap);
+int launch_fs_dshard_finalize_raw(mclhip_ctx* c, const void* d_all_rec, const ShardLayout& lay, int cap, double* d_last_out);
 int launch_shard_finalize(mclhip_ctx* c, const void* d_records, int64_t nrec, void* d_bases, uint64_t P_off,
                           uint32_t F_off, const unsigned long long* d_meta = nullptr);
 int launch_count_below(mclhip_ctx* c, const double* d_U, int nu, int64_t* d_counts);

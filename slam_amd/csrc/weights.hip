@@ -1117,6 +1117,49 @@ int launch_dshard_scan(mclhip_ctx* c, const double* d_all_chunks, const ShardLay
 
 int launch_plan_drawn(mclhip_ctx* c, const ShardLayout& lay, double r, int64_t* d_counts, const unsigned long long* meta);
 
+// ---- FastSLAM over several GPUs, device-driven: the weight vector is normalised by the Python-order sum of
+// fast_slam1.py:411-418 (the last running sum of the raw weights, floored at 1e-8), not by np.sum.  Two rounds of the
+// record exchange: raw weights (lasts == nullptr: nothing is divided, scal[0] = 1), then the weights over that sum.
+__global__ void fs_shard_totals_kernel(const double* __restrict__ all_chunks, const double* __restrict__ lasts, ShardLayout lay,
+                                       double* __restrict__ scal) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double below = 0.0;                                        // approximate: only places the local scan's error bound
+  for (int r = 0; r < lay.rank; ++r) {
+    const double* src = all_chunks + (size_t)r * lay.cmax;
+    for (int j = 0; j < lay.nchunks[r]; ++j) below = below + src[j];
+  }
+  const double total = lasts ? fmax(1e-8, lasts[2 * (lay.world - 1)]) : 1.0;   // max(1e-8, sum_w) (:415); lasts: (sum, flag) per rank
+  scal[0] = total;
+  scal[5] = below / total;
+}
+
+int launch_fs_dshard_scan(mclhip_ctx* c, const double* d_all_chunks, const double* d_lasts, const ShardLayout& lay,
+                          void* d_rec_out, int cap) {
+  hipLaunchKernelGGL(fs_shard_totals_kernel, dim3(1), dim3(64), 0, c->stream, d_all_chunks, d_lasts, lay, c->scal);
+  MCL_TRY_W(launch_shard_scan(c, 0.0, 0.0, c->first_index, c->scal + 5));
+  hipLaunchKernelGGL(export_records_kernel, dim3(1), dim3(256), 0, c->stream, (const unsigned long long*)c->kscan,
+                     c->fscan, (const IrrRecord*)c->irr, c->M, cap, (unsigned long long*)d_rec_out);
+  MCL_HIP(c, hipGetLastError());
+  return MCLHIP_OK;
+}
+
+// out[0] = this rank's last running sum, out[1] = 1.0 if some rank had more records than the exchange holds
+__global__ void fs_last_sum_kernel(const double* __restrict__ cdf, int64_t n, const unsigned long long* __restrict__ meta,
+                                   double* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = cdf[n - 1]; out[1] = meta[3] ? 1.0 : 0.0; }
+}
+
+// first round: the global record list of the raw weights, this rank's exact running sums, its last one -> d_last_out
+int launch_fs_dshard_finalize_raw(mclhip_ctx* c, const void* d_all_rec, const ShardLayout& lay, int cap, double* d_last_out) {
+  unsigned long long* meta = reinterpret_cast<unsigned long long*>(c->small_i);
+  hipLaunchKernelGGL(merge_records_kernel, dim3(1), dim3(256), 0, c->stream, (const unsigned long long*)d_all_rec,
+                     lay.world, lay.rank, cap, (IrrRecord*)c->g_records, meta);
+  MCL_TRY_W(launch_shard_finalize(c, c->g_records, 0, c->g_bases, 0, 0, meta));
+  hipLaunchKernelGGL(fs_last_sum_kernel, dim3(1), dim3(64), 0, c->stream, (const double*)c->cdf_exact, c->M, meta, d_last_out);
+  MCL_HIP(c, hipGetLastError());
+  return MCLHIP_OK;
+}
+
 int launch_dshard_finalize(mclhip_ctx* c, const void* d_all_rec, const ShardLayout& lay, int cap, double r,
                            int64_t* d_counts) {
   unsigned long long* meta = reinterpret_cast<unsigned long long*>(c->small_i);   // [4] of the 1024-entry staging

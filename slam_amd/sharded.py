@@ -155,6 +155,31 @@ def sequential_sum(values):
     return float(t)
 
 
+def drive_exchanges(gen, torch, dist, stream):
+    """Serve the exchanges a device-step generator asks for with torch.distributed, on the step's stream."""
+    with torch.cuda.stream(stream):
+        try:
+            req = next(gen)
+            while True:
+                op = req[0]
+                val = None
+                if op == "all_reduce_max":
+                    dist.all_reduce(req[1], op=dist.ReduceOp.MAX)
+                elif op == "all_gather":
+                    dist.all_gather_into_tensor(req[1], req[2])
+                elif op == "all_gather_read":
+                    dist.all_gather_into_tensor(req[1], req[2])
+                    val = req[1].cpu().numpy()
+                elif op == "all_to_all":
+                    send, sc, rc = req[1], req[2], req[3]
+                    val = torch.empty((max(int(sum(rc)), 1), send.shape[1]), dtype=send.dtype, device=send.device)
+                    dist.all_to_all_single(val[:int(sum(rc))], send[:int(sum(sc))], [int(c) for c in rc],
+                                           [int(c) for c in sc])
+                req = gen.send(val)
+        except StopIteration as done:
+            return done.value
+
+
 class ShardedFilter:
     """Drives one MCL update per call over `world` ranks."""
 
@@ -262,29 +287,7 @@ class ShardedFilter:
         return True
 
     def _drive(self, gen):
-        """Serve the exchanges of one rank's _device_step with torch.distributed on the step's stream."""
-        torch, dist = self._torch, self.dist
-        with torch.cuda.stream(self.stream):
-            try:
-                req = next(gen)
-                while True:
-                    op = req[0]
-                    val = None
-                    if op == "all_reduce_max":
-                        dist.all_reduce(req[1], op=dist.ReduceOp.MAX)
-                    elif op == "all_gather":
-                        dist.all_gather_into_tensor(req[1], req[2])
-                    elif op == "all_gather_read":
-                        dist.all_gather_into_tensor(req[1], req[2])
-                        val = req[1].cpu().numpy()
-                    elif op == "all_to_all":
-                        send, sc, rc = req[1], req[2], req[3]
-                        val = torch.empty((max(int(sum(rc)), 1), send.shape[1]), dtype=torch.float64, device=send.device)
-                        dist.all_to_all_single(val[:int(sum(rc))], send[:int(sum(sc))], [int(c) for c in rc],
-                                               [int(c) for c in sc])
-                    req = gen.send(val)
-            except StopIteration as done:
-                return done.value
+        return drive_exchanges(gen, self._torch, self.dist, self.stream)
 
     def step(self, v, omega, dt, alpha, z_meas, r, seed=0, noise_ints=None, want_idx=False):
         """r = (uniform draw) / M_total, identical on every rank."""
@@ -358,11 +361,17 @@ class ShardedFilter:
 class ShardedFastSLAM:
     """One FastSLAM 1.0 filter over `world` ranks (13_fast_slam/fast_slam1.py:240-433): every rank runs
     the per-particle step on its contiguous range, the ranks then agree on the weight sum and the
-    running sums in the reference's strictly sequential order, and resampled particles travel as
-    pose rows plus feature rows in two all-to-all exchanges.  The host combines the ranks' small
-    results (the exchanges are the ones of ShardedFilter's host-combined step)."""
+    running sums in the reference's strictly sequential order, and the particles that some position
+    draws travel as pose rows plus feature rows in two all-to-all exchanges.
 
-    def __init__(self, ctx, dist, rank, world, m_local, capacity):
+    Two drivers of the same arithmetic: device-driven (default under RCCL) -- every library call only
+    enqueues, the collectives run on device tensors, one device-to-host read per step -- and
+    host-combined (gloo; the exchanges are the ones of ShardedFilter's host-combined step)."""
+
+    RECORD_CAP = 4096    # irregular records per rank in the device-driven exchange: the running sum of the raw weights
+                         # crosses every binade between the smallest weight and the total at most once on ALL ranks together
+
+    def __init__(self, ctx, dist, rank, world, m_local, capacity, device_path=None):
         self.ctx, self.dist, self.rank, self.world = ctx, dist, rank, world
         ctx.fs_init(int(m_local), int(capacity))
         self.capacity = int(capacity)
@@ -377,6 +386,92 @@ class ShardedFastSLAM:
         ctx.shard_set(self.firsts[rank], self.m_total)
         self.words = ctx.fs_row_words()
         self.last_idx = None
+        if device_path is None:
+            device_path = self.coll.backend == "nccl"
+        self.device_path = bool(device_path)
+        if self.device_path:
+            self._device_setup(self.coll.torch, self.coll.dev)
+
+    @classmethod
+    def for_layout(cls, ctx, rank, sizes, capacity):
+        """A device-path filter for rank `rank` of a known layout, without a process group: whoever drives its
+        _device_step generator supplies the exchanges (several ranks inside one process, for tests)."""
+        import torch
+        self = cls.__new__(cls)
+        self.ctx, self.dist, self.rank, self.world, self.coll = ctx, None, rank, len(sizes), None
+        ctx.fs_init(int(sizes[rank]), int(capacity))
+        self.capacity = int(capacity)
+        self.sizes = [int(n) for n in sizes]
+        self.firsts = [int(x) for x in np.concatenate([[0], np.cumsum(self.sizes)])]
+        self.m_total = self.firsts[-1]
+        ctx.shard_set(self.firsts[rank], self.m_total)
+        self.words = ctx.fs_row_words()
+        self.last_idx, self.device_path = None, True
+        self._device_setup(torch, torch.device("cuda", torch.cuda.current_device()))
+        return self
+
+    # -- device-driven step ---------------------------------------------------------------------
+    def _device_setup(self, torch, dev):
+        W, m_local = self.world, self.sizes[self.rank]
+        cmax = max((n + CHUNK - 1) // CHUNK for n in self.sizes)
+        rb = 2 + 3 * self.RECORD_CAP          # 64-bit words per rank: header + records of 24 bytes
+        self._torch = torch
+        self.stream = torch.cuda.Stream(device=dev)
+        f64, i64 = torch.float64, torch.int64
+        self.t_chunks = torch.zeros(cmax, dtype=f64, device=dev)
+        self.t_all_chunks = torch.zeros(W * cmax, dtype=f64, device=dev)
+        self.t_rec = torch.zeros(rb, dtype=i64, device=dev)
+        self.t_all_rec = torch.zeros(W * rb, dtype=i64, device=dev)
+        self.t_last = torch.zeros(2, dtype=f64, device=dev)                 # last running sum of the raw weights, overflow flag
+        self.t_all_last = torch.zeros(2 * W, dtype=f64, device=dev)
+        self.t_plan = torch.zeros(W + 1 + 3, dtype=i64, device=dev)         # rows per destination, record overflow; then the select info
+        self.t_all_plan = torch.zeros(W * (W + 4), dtype=i64, device=dev)
+        self.t_send = torch.empty((m_local + W, 6), dtype=f64, device=dev)  # every local row once, boundary rows twice
+        self.rows_sent_total = self.rows_sent_off_rank = self.steps_done = 0
+        self._keep = None
+        self.ctx.set_stream(self.stream.cuda_stream)
+
+    def _device_step(self, v, omega, dt, alpha, truth_r, truth_phi, truth_valid, ints, normals, r, seed):
+        """Generator: enqueues this rank's work and yields the exchanges it needs, in the vocabulary of
+        ShardedFilter._device_step.  One host read: the gathered plan (row counts, longest travelling feature list,
+        overflow flags)."""
+        ctx, rank, world, cap, torch = self.ctx, self.rank, self.world, self.RECORD_CAP, self._torch
+        ctx.fs_dshard_kernel(v, omega, dt, alpha, truth_r, truth_phi, truth_valid, ints, normals, seed, self.t_chunks.data_ptr())
+        yield ("all_gather", self.t_all_chunks, self.t_chunks)
+        # sum_w exactly as `for m in range(M): sum_w += Y[m].w` forms it (:411-413): the last running sum of the raw weights
+        ctx.fs_dshard_scan(self.t_all_chunks.data_ptr(), None, self.firsts, rank, self.t_rec.data_ptr(), cap)
+        yield ("all_gather", self.t_all_rec, self.t_rec)
+        ctx.fs_dshard_finalize_raw(self.t_all_rec.data_ptr(), self.firsts, rank, cap, self.t_last.data_ptr())
+        yield ("all_gather", self.t_all_last, self.t_last)
+        # w /= max(1e-8, sum_w) (:415-418) and the running sums c_i (:421-428)
+        ctx.fs_dshard_scan(self.t_all_chunks.data_ptr(), self.t_all_last.data_ptr(), self.firsts, rank, self.t_rec.data_ptr(), cap)
+        yield ("all_gather", self.t_all_rec, self.t_rec)
+        ctx.dshard_finalize(self.t_all_rec.data_ptr(), self.firsts, rank, cap, r, self.t_plan.data_ptr())
+        # pose rows of the particles some position draws; :318-404 for exactly those
+        ctx.fs_dshard_select(world, self.t_plan.data_ptr(), self.t_last.data_ptr(), self.t_send.data_ptr(),
+                             self.t_plan.data_ptr() + 8 * (world + 1))
+        plan = yield ("all_gather_read", self.t_all_plan, self.t_plan)
+        plan = plan.reshape(world, world + 4)
+        if plan[:, world].any() or plan[:, world + 3].any():
+            raise _lib.MclHipError("more irregular records on a rank than the fixed exchange holds (ShardedFastSLAM.RECORD_CAP)")
+        if plan[:, world + 2].any():
+            raise _lib.MclHipError("a particle ran out of feature slots: raise the capacity")
+        send_counts = [int(c) for c in plan[rank, :world]]
+        recv_counts = [int(c) for c in plan[:world, rank]]
+        n_send, L = sum(send_counts), sum(recv_counts)
+        most = max(1, min(int(plan[:, world + 1].max()), self.capacity))
+        self.steps_done += 1
+        self.rows_sent_total += n_send
+        self.rows_sent_off_rank += n_send - send_counts[rank]
+        ctx.fs_set_row_slots(most)           # feature rows as long as the longest list that travels, not as the capacity
+        self.words = ctx.fs_row_words()
+        fsend = torch.empty((max(n_send, 1), self.words), dtype=torch.int64, device=self.t_send.device)
+        ctx.fs_dshard_pack(n_send, fsend.data_ptr())
+        recv = yield ("all_to_all", self.t_send, send_counts, recv_counts)
+        frecv = yield ("all_to_all", fsend, send_counts, recv_counts)
+        ctx.fs_dshard_unpack(recv.data_ptr(), frecv.data_ptr(), L, r, most)
+        self._keep = (fsend, recv, frecv)    # alive until the next step has been enqueued behind them
+        return True
 
     def _exact_running_sums(self, divisor, all_chunks):
         """w /= divisor on every rank, then the strictly sequential running sum of the GLOBAL weight
@@ -403,6 +498,11 @@ class ShardedFastSLAM:
         """ints / normals: this rank's slice of the pre-drawn numbers (or None: device generators keyed
         by the global particle index).  r = np.random.rand() * 1/M_total, identical on every rank."""
         ctx, co, rank, world = self.ctx, self.coll, self.rank, self.world
+        if self.device_path:
+            drive_exchanges(self._device_step(v, omega, dt, alpha, truth_r, truth_phi, truth_valid, ints, normals, r, seed),
+                            self._torch, self.dist, self.stream)
+            self.last_idx = ctx.get_indices() if want_idx else None
+            return
         ctx.fs_shard_kernel(v, omega, dt, alpha, truth_r, truth_phi, truth_valid, ints, normals, seed)
         chunks = ctx.shard_weights(_lib.W_PRODUCT, 0.0)          # approximate offsets only
         all_chunks = [np.frombuffer(x, np.float64) for x in co.allgather_bytes(chunks.tobytes())]

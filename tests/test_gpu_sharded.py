@@ -105,6 +105,46 @@ def test_rccl_path_with_device_tensors_on_one_rank(device_path):
     assert np.array_equal(res["X"], Xr) and np.array_equal(res["w"], wr)
 
 
+def _run_lockstep(torch, gens, settle):
+    """Runs the device-step generators of several ranks side by side, serving every exchange they yield with plain
+    tensor operations; returns what each generator returned."""
+    W = len(gens)
+    req = [next(g) for g in gens]
+    done = [None] * W
+    while any(d is None for d in done):
+        settle()
+        op = req[0][0]
+        assert all(q[0] == op for q in req)
+        vals = [None] * W
+        if op == "all_reduce_max":
+            m = torch.stack([q[1] for q in req]).max(0).values
+            for q in req:
+                q[1].copy_(m)
+        elif op == "all_gather":
+            cat = torch.cat([q[2] for q in req])
+            for q in req:
+                q[1].copy_(cat)
+        elif op == "all_gather_read":
+            cat = torch.cat([q[2] for q in req])
+            vals = [cat.cpu().numpy() for _ in req]
+        elif op == "all_to_all":
+            offs = [np.concatenate([[0], np.cumsum(q[2])]).astype(int) for q in req]
+            for d in range(W):
+                parts = [req[s][1][offs[s][d]:offs[s][d + 1]] for s in range(W)]
+                assert [len(p) for p in parts] == [int(c) for c in req[d][3]]
+                rows = torch.cat(parts) if sum(len(p) for p in parts) else \
+                    torch.empty((1, req[d][1].shape[1]), dtype=req[d][1].dtype, device="cuda")
+                vals[d] = rows.contiguous()
+        settle()
+        for k in range(W):
+            try:
+                req[k] = gens[k].send(vals[k])
+            except StopIteration as e:
+                done[k] = e.value
+    settle()
+    return done
+
+
 def _lockstep_fn(rank, world, dist, sizes, z_meas, record_cap, flat=False):
     """Several ranks of the device-driven step inside ONE process (one context per rank on the same
     GPU); the exchanges between them are done here with plain tensor operations, so that the
@@ -131,37 +171,7 @@ def _lockstep_fn(rank, world, dist, sizes, z_meas, record_cap, flat=False):
             f.b.ctx.sync()
         torch.cuda.synchronize()
 
-    req = [next(g) for g in gens]
-    done = [None] * W
-    while any(d is None for d in done):
-        settle()
-        op = req[0][0]
-        vals = [None] * W
-        if op == "all_reduce_max":
-            m = torch.stack([q[1] for q in req]).max(0).values
-            for q in req:
-                q[1].copy_(m)
-        elif op == "all_gather":
-            cat = torch.cat([q[2] for q in req])
-            for q in req:
-                q[1].copy_(cat)
-        elif op == "all_gather_read":
-            cat = torch.cat([q[2] for q in req])
-            vals = [cat.cpu().numpy() for _ in req]
-        elif op == "all_to_all":
-            offs = [np.concatenate([[0], np.cumsum(q[2])]).astype(int) for q in req]
-            for d in range(W):
-                parts = [req[s][1][offs[s][d]:offs[s][d + 1]] for s in range(W)]
-                assert [len(p) for p in parts] == [int(c) for c in req[d][3]]
-                rows = torch.cat(parts) if sum(len(p) for p in parts) else torch.empty((1, 6), dtype=torch.float64, device="cuda")
-                vals[d] = rows.contiguous()
-        settle()
-        for k in range(W):
-            try:
-                req[k] = gens[k].send(vals[k])
-            except StopIteration as e:
-                done[k] = e.value
-    settle()
+    done = _run_lockstep(torch, gens, settle)
     out = []
     for k, f in enumerate(filt):
         Xo, wo, _ = f.b.ctx.get_particles()
@@ -287,3 +297,89 @@ def test_fastslam_over_ranks_equals_one_context(sizes):
         assert np.array_equal(np.concatenate([x["idx"][t] for x in res]), ref_idx[t]), t
     for k in ("pose", "w", "nfeat", "new_id", "f_m", "f_cov", "f_i", "f_w", "f_id"):
         assert np.array_equal(np.concatenate([x[k] for x in res]), want[k]), k
+
+
+def _fs_lockstep_fn(rank, world, dist, sizes, steps):
+    """Several ranks of the device-driven FastSLAM step inside one process, one context per rank on the same GPU."""
+    import torch
+    from oracle import fastslam_oracle as F
+    from slam_amd import _lib
+    from slam_amd.sharded import ShardedFastSLAM
+    torch.cuda.set_device(0)
+    M, W = sum(sizes), len(sizes)
+    filt = [ShardedFastSLAM.for_layout(_lib.Context(0, _lib.F64), k, sizes, 16) for k in range(W)]
+
+    def settle():
+        for f in filt:
+            f.ctx.sync()
+        torch.cuda.synchronize()
+
+    idx = []
+    for (ut, tr, tp, tv, ints, nrm, r) in _fs_inputs(M, steps):
+        gens = []
+        for k, f in enumerate(filt):
+            sl = slice(f.firsts[k], f.firsts[k + 1])
+            gens.append(f._device_step(ut[0], ut[1], F.DT, F.ALPHA, tr, tp, tv, ints[sl], nrm[sl], r, 0))
+        assert all(_run_lockstep(torch, gens, settle))
+        idx.append(np.concatenate([f.ctx.get_indices() for f in filt]))
+    out = [f.ctx.fs_get_state() for f in filt]
+    return {"idx": idx, "state": out, "rows": [(f.rows_sent_total, f.rows_sent_off_rank) for f in filt]}
+
+
+@pytest.mark.parametrize("sizes", [(8192, 8192), (8192, 8192, 3000), (8192,) * 5])
+def test_device_driven_fastslam_of_several_ranks_equals_one_context(sizes):
+    """The device-driven FastSLAM step (no host in the loop but for one read of the gathered plan), ranks in lockstep
+    inside one process: ancestors and the whole state, feature slots included, equal the single-context filter bit for
+    bit after four steps; only drawn particles travel."""
+    from oracle import fastslam_oracle as F
+    from slam_amd import _lib
+    M, steps = sum(sizes), 4
+    ref = _lib.Context(0, _lib.F64)
+    ref.fs_init(M, 16)
+    ref_idx = []
+    for (ut, tr, tp, tv, ints, nrm, r) in _fs_inputs(M, steps):
+        ref_idx.append(ref.fs_step(ut[0], ut[1], F.DT, F.ALPHA, tr, tp, tv, ints, nrm, r, want_idx=True))
+    want = ref.fs_get_state()
+    res = run_ranks(_fs_lockstep_fn, 1, sizes, steps, backend="nccl")[0]
+    for t in range(steps):
+        assert np.array_equal(res["idx"][t], ref_idx[t]), t
+    for k in ("pose", "w", "nfeat", "new_id", "f_m", "f_cov", "f_i", "f_w", "f_id"):
+        assert np.array_equal(np.concatenate([x[k] for x in res["state"]]), want[k]), k
+    sent = sum(a for a, _ in res["rows"])
+    print("%d ranks, %d particles, %d steps: %d rows exchanged (%d between ranks)" % (len(sizes), M, steps, sent, sum(b for _, b in res["rows"])))
+    assert sent <= steps * (M + len(sizes) ** 2)
+
+
+def _fs_rccl_rank_fn(rank, world, dist, M, steps):
+    import torch
+    from oracle import fastslam_oracle as F
+    from slam_amd import _lib
+    from slam_amd.sharded import ShardedFastSLAM
+    torch.cuda.set_device(0)
+    ctx = _lib.Context(0, _lib.F64)
+    f = ShardedFastSLAM(ctx, dist, rank, world, M, 16)
+    assert f.device_path
+    idx = []
+    for (ut, tr, tp, tv, ints, nrm, r) in _fs_inputs(M, steps):
+        f.step(ut[0], ut[1], F.DT, F.ALPHA, tr, tp, tv, ints, nrm, r, want_idx=True)
+        idx.append(f.last_idx)
+    st = ctx.fs_get_state()
+    st["idx"] = idx
+    return st
+
+
+def test_device_driven_fastslam_under_rccl_on_one_rank():
+    """The same step through torch.distributed on device tensors (RCCL, a group of one on the box's GPU)."""
+    from oracle import fastslam_oracle as F
+    from slam_amd import _lib
+    M, steps = 8192 + 3000, 4
+    ref = _lib.Context(0, _lib.F64)
+    ref.fs_init(M, 16)
+    ref_idx = [ref.fs_step(ut[0], ut[1], F.DT, F.ALPHA, tr, tp, tv, ints, nrm, r, want_idx=True)
+               for (ut, tr, tp, tv, ints, nrm, r) in _fs_inputs(M, steps)]
+    want = ref.fs_get_state()
+    res = run_ranks(_fs_rccl_rank_fn, 1, M, steps, backend="nccl")[0]
+    for t in range(steps):
+        assert np.array_equal(res["idx"][t], ref_idx[t]), t
+    for k in ("pose", "w", "nfeat", "new_id", "f_m", "f_cov", "f_i", "f_w", "f_id"):
+        assert np.array_equal(res[k], want[k]), k
