@@ -80,6 +80,21 @@ __device__ inline double wave_sum(double v) {
                               (unsigned int)__builtin_amdgcn_readlane((int)__double_as_longlong(v), 63));
 }
 
+// float32 sum over the 64 lanes, valid in every lane
+__device__ inline float wave_sum_f32(float v) {
+  auto shifted = [](float x, auto ctrl, auto rmask) {
+    return __int_as_float(MCL_DPP_I32(0, __float_as_int(x), decltype(ctrl)::value, decltype(rmask)::value));
+  };
+  using std::integral_constant;
+  v += shifted(v, integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{});
+  v += shifted(v, integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{});
+  v += shifted(v, integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{});
+  v += shifted(v, integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{});
+  v += shifted(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});
+  v += shifted(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // Bearing of (dx, dy) in [0, 2pi), float32, |error| < 1e-6 rad for finite inputs (0 for dx = dy = 0,
 // as atan2 gives).  Only used to pick candidate beams: decisions within 1e-5 rad of a sector edge
 // are taken again with the float64 atan2.  Odd minimax polynomial of degree 15 for atan on [0, 1]
@@ -233,6 +248,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
   const double inv_two_pi = 1.0 / kTwoPi;
   const double inv_res_x = 1.0 / P.res_x, inv_res_y = 1.0 / P.res_y;
   const float reachf = (float)reach, inv_bwf = (float)P.inv_bw, ext_minf = (float)P.ext_min;
+  const float ts_minf = (float)P.ts_min, spanf = (float)span, inv_two_pif = (float)inv_two_pi;
   const int G = P.G, NX = P.G + B;
   const bool seam = span < kTwoPi - 1e-9;   // images of the top beams exist: one window covers both sides of the seam
   const float sure_in = (float)(P.half - kEdgeEps), sure_out = (float)(P.half + kEdgeEps);
@@ -275,6 +291,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
       }
     }
     const float xf = (float)x, yf = (float)y;
+    const float thf = (float)th;
 
     // one cell against the beam table
     auto match_cell = [&](unsigned int e, bool valid, int phase) {
@@ -286,13 +303,24 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
       COUNT(1);
       if (valid && r2 <= P.r2max) {       // :127
         COUNTL(2);
-        const double aa = (double)bearing_f32((float)dy, (float)dx);
+        const float aaf = bearing_f32((float)dy, (float)dx);
         const unsigned long long r2bits = (unsigned long long)__double_as_longlong(r2);
         const unsigned long long cellbits = (unsigned long long)((unsigned int)row * (unsigned int)P.W + (unsigned int)col);
         // beams whose table angle lies within `reach` of aa - th + c*2pi, c in {-1, 0, 1}
-        const double psi = (aa - th) - P.ts_min;
-        int c_lo = (int)ceil((-reach - psi) * inv_two_pi);
-        int c_hi = (int)floor((span + reach - psi) * inv_two_pi);
+        double psi = 0.0;
+        float psif = 0.0f;
+        int c_lo, c_hi;
+        if constexpr (FAST) {
+          // float32 throughout: the heading of a float32 state is exact in float32, the bearing is a float32 already,
+          // and which windows are looked at has 1e-5 rad of slack (reach against the edges that are tested)
+          psif = (aaf - thf) - ts_minf;
+          c_lo = (int)ceilf((-reachf - psif) * inv_two_pif);
+          c_hi = (int)floorf((spanf + reachf - psif) * inv_two_pif);
+        } else {
+          psi = ((double)aaf - th) - P.ts_min;
+          c_lo = (int)ceil((-reach - psi) * inv_two_pi);
+          c_hi = (int)floor((span + reach - psi) * inv_two_pi);
+        }
         c_lo = c_lo < -1 ? -1 : c_lo;
         c_hi = c_hi > 1 ? 1 : c_hi;
         double a_exact = 0.0;
@@ -305,7 +333,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
           // window centre relative to the smallest table angle; small whenever the window can
           // hold a beam, so float32 is enough for everything but the edge cases
           COUNT(3);
-          const float centref = (float)(psi + (double)c * kTwoPi);
+          const float centref = FAST ? psif + (float)c * 6.2831853071795865f : (float)(psi + (double)c * kTwoPi);
           const float lof = centref - reachf;
           int i0 = 0;
           if (lof > ext_minf) {
@@ -565,7 +593,8 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
         }
       }
       if (nfac) l2s += log2_of_product(prod);
-      const double lsd = wave_sum(l2s) * 0.6931471805599453;
+      // (64 lane totals of a few tens each: a float32 sum is good to 3e-7 of the result)
+      const double lsd = (double)wave_sum_f32((float)l2s) * 0.6931471805599453;
       if (lane == 0) logw_out[p] = on_free ? lsd : -INFINITY;
     } else {
       typedef T R;  // likelihood arithmetic follows the state dtype
