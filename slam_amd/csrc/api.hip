@@ -80,6 +80,8 @@ RayParams make_ray_params(const mclhip_ctx* c) {
   P.tab_sorted = c->tab_sorted; P.perm = c->perm; P.lut = c->lut;
   P.ts_min = c->ts_min; P.ts_max = c->ts_max; P.inv_bw = c->inv_bw;
   P.relx = c->relx; P.G = c->G; P.ext_min = c->ext_min;
+  P.iv_NE = c->iv_NE; P.iv_NB = c->iv_NB; P.iv_edge = c->iv_edge; P.iv_beam = c->iv_beam; P.iv_lut = c->iv_lut;
+  P.iv_origin = c->iv_origin; P.iv_th_hi = c->iv_th_hi;
   P.half = c->half;
   P.two_pi_lo = M_PI * 2 - c->half;  // mc_localization.py:149
   P.two_pi_hi = M_PI * 2 + c->half;
@@ -341,7 +343,7 @@ void mclhip_destroy(mclhip_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   fs_release(c);
-  void* ptrs[] = {c->obst, c->freeb, c->tile_off, c->cells, c->nbr_off, c->nbr_cells, c->tab_sorted, c->tab_orig, c->perm, c->inv_perm, c->lut, c->relx, c->zt, c->etalam, c->zmeas_stage, c->ring,
+  void* ptrs[] = {c->obst, c->freeb, c->tile_off, c->cells, c->nbr_off, c->nbr_cells, c->tab_sorted, c->tab_orig, c->perm, c->inv_perm, c->lut, c->relx, c->iv_edge, c->iv_beam, c->iv_lut, c->zt, c->etalam, c->zmeas_stage, c->ring,
                   c->px[0], c->px[1], c->py[0], c->py[1], c->pth[0], c->pth[1], c->w[0], c->w[1], c->logw, c->pm,
                   c->sx, c->sy, c->sth, c->sw, c->chunk_sums, c->scal, c->cdf_approx, c->cdf_exact, c->kscan,
                   c->fscan, c->blk_a, c->blk_b, c->irr, c->bases, c->idx, c->noise, c->counters, c->range_noise, c->inj_rows, c->stamps,
@@ -491,6 +493,63 @@ int mcl::set_sensor_table(mclhip_ctx* c, const double* tab_rad, int B, double z_
     MCL_HIP(c, hipMemcpy(c->inv_perm, inv.data(), B * sizeof(uint16_t), hipMemcpyHostToDevice));
   }
   MCL_HIP(c, hipMemcpy(c->lut, lut.data(), NB * sizeof(uint16_t), hipMemcpyHostToDevice));
+  {
+    // Sector intervals.  Available when every beam angle lies in [0, 2 pi) and the sectors are proper arcs; edges that
+    // agree to 1e-9 rad count as one (a bearing that close to either is decided by the exact test anyway).
+    c->iv_NE = 0; c->iv_NB = 0;
+    const bool usable = c->ts_min >= 0.0 && c->ts_max < two_pi && half > 16.0 * kEdgeEps && half < 0.5 * M_PI;
+    if (usable) {
+      const double origin = c->ts_min - half;
+      std::vector<double> all;
+      auto reduced = [&](double a) { double v = a - origin; while (v >= two_pi) v -= two_pi; while (v < 0.0) v += two_pi; return v; };
+      for (int k = 0; k < B; ++k) { all.push_back(reduced(ts[k] - half)); all.push_back(reduced(ts[k] + half)); }
+      std::sort(all.begin(), all.end());
+      std::vector<double> edge;
+      for (double v : all)
+        if (edge.empty() || v - edge.back() > 1e-9) edge.push_back(v);
+      if (edge.size() > 1 && two_pi - edge.back() <= 1e-9) edge.pop_back();        // the same edge as 0 from the other side
+      const int NE = (int)edge.size();
+      auto index_of = [&](double v) {            // the merged edge nearest to v on the circle
+        int best = 0; double bd = 1e9;
+        for (int m = 0; m < NE; ++m) {
+          double d = std::fabs(edge[m] - v); d = std::min(d, two_pi - d);
+          if (d < bd) { bd = d; best = m; }
+        }
+        return best;
+      };
+      bool ok = NE >= 2 && NE <= 255 && edge[0] <= 1e-9;
+      std::vector<uint16_t> beam(B);
+      for (int k = 0; k < B && ok; ++k) {
+        const int m0 = index_of(reduced(ts[k] - half)), m1 = index_of(reduced(ts[k] + half));
+        const int cnt = (m1 - m0 + NE) % NE;
+        if (cnt < 1 || cnt > 255) ok = false;
+        beam[k] = (uint16_t)(m0 | (cnt << 8));
+      }
+      if (ok) {
+        int NBI = 1;
+        while (NBI < 4 * NE) NBI <<= 1;
+        std::vector<float> ef(NE + 1);
+        for (int m = 0; m < NE; ++m) ef[m] = (float)edge[m];
+        ef[0] = 0.0f;
+        ef[NE] = (float)two_pi;
+        std::vector<uint8_t> ilut(NBI);
+        for (int b = 0; b < NBI; ++b) {
+          const float lower = (float)(two_pi * b / NBI);
+          int m = 0;
+          while (m + 1 < NE && ef[m + 1] <= lower) ++m;
+          ilut[b] = (uint8_t)m;
+        }
+        MCL_TRY(dev_alloc(c, &c->iv_edge, ef.size() * sizeof(float)));
+        MCL_TRY(dev_alloc(c, &c->iv_beam, B * sizeof(uint16_t)));
+        MCL_TRY(dev_alloc(c, &c->iv_lut, NBI));
+        MCL_HIP(c, hipMemcpy(c->iv_edge, ef.data(), ef.size() * sizeof(float), hipMemcpyHostToDevice));
+        MCL_HIP(c, hipMemcpy(c->iv_beam, beam.data(), B * sizeof(uint16_t), hipMemcpyHostToDevice));
+        MCL_HIP(c, hipMemcpy(c->iv_lut, ilut.data(), NBI, hipMemcpyHostToDevice));
+        c->iv_NE = NE; c->iv_NB = NBI; c->iv_origin = origin;
+        c->iv_th_hi = two_pi - 2.0 * half - 1e-3;
+      }
+    }
+  }
   MCL_HIP(c, hipMemset(c->zt, 0, B * sizeof(double)));
   MCL_HIP(c, hipMemset(c->etalam, 0, B * sizeof(double)));
   return MCLHIP_OK;

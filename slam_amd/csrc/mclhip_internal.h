@@ -50,6 +50,17 @@ struct RayParams {
   double ext_min;            // relx[0] as float64 (<= 0): lower end of the bucket index
   double ts_min, ts_max, inv_bw;
   double half, two_pi_lo, two_pi_hi;
+  // Sector intervals (float32-mixture instantiation): the 2B sector edges, sorted around the circle, cut it into
+  // intervals inside each of which the set of sectors that hold a bearing does not change -- a contiguous run of beams.
+  // A cell that is not within rounding of an edge then costs ONE minimum (its interval's) instead of one per beam, and
+  // a beam's range is the smallest of the few intervals its sector spans.  iv_NE == 0: not available for this table.
+  int iv_NE, iv_NB;            // intervals (<= 255), buckets of the look-up (a power of two)
+  const float* iv_edge;        // [NE + 1] lower edge of every interval, measured from iv_origin; iv_edge[NE] = 2 pi
+  const uint16_t* iv_beam;     // [B] first interval | number of intervals << 8 of the beam at sorted position k
+  const uint8_t* iv_lut;       // [NB] bucket -> last interval that starts at or below the bucket's lower edge
+  double iv_origin;            // angle of edge 0 (the lowest sector edge)
+  double iv_th_hi;             // headings in [0, iv_th_hi] take this path: there the reference's predicate (one turn of
+                               // slack, mc_localization.py:148-149) is the circular one
   // beam mixture
   const double* zt;      // measured range per beam, in sorted-angle order
   const double* etalam;  // eta_short * lambda_short per beam, in sorted-angle order
@@ -121,6 +132,8 @@ struct mclhip_ctx {
   uint16_t* perm = nullptr;
   uint16_t* inv_perm = nullptr;
   uint16_t* lut = nullptr;
+  float* iv_edge = nullptr; uint16_t* iv_beam = nullptr; uint8_t* iv_lut = nullptr;   // sector intervals (see RayParams)
+  int iv_NE = 0, iv_NB = 0; double iv_origin = 0.0, iv_th_hi = 0.0;
   float* relx = nullptr;
   int G = 0;
   double ext_min = 0;

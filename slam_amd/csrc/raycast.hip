@@ -158,6 +158,9 @@ __device__ __attribute__((noinline)) double slow_log(double v) { return log(v); 
 #endif
 // The float32-mixture instantiation needs fewer registers: seven waves per SIMD (72 VGPRs).  Measured at 2^20 x 180:
 // 5 waves 1.51 ms, 6 waves 1.43 ms, 7 waves 1.40 ms, 8 waves 1.74 ms.
+#ifndef MCL_FAST_INTERVALS
+#define MCL_FAST_INTERVALS 1
+#endif
 #ifndef MCL_FAST_WAVES
 #define MCL_FAST_WAVES 7
 #endif
@@ -196,7 +199,10 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
   const int NXP = P.G + B + kGroup;                              // extended table + one group of padding
   const int RS = NXP + NE + (GRID ? B : 0);                      // per wave: minima per table entry, then (GRID) per entry, and a double per class
   unsigned long long* s_aux_all = s_rmin_all + (size_t)WPB * RS;
-  unsigned int* s_walk_all = reinterpret_cast<unsigned int*>(s_aux_all + (size_t)((STAGE || PRODUCT) ? WPB * RS : 0));
+  // FAST: per wave, the smallest squared distance per sector interval (see RayParams::iv_*)
+  const int IVN = FAST ? P.iv_NE : 0;
+  unsigned long long* s_imin_all = s_aux_all + (size_t)((STAGE || PRODUCT) ? WPB * RS : 0);
+  unsigned int* s_walk_all = reinterpret_cast<unsigned int*>(s_imin_all + (size_t)WPB * IVN);
   float* s_relx = reinterpret_cast<float*>(s_walk_all + (size_t)WPB * kWaveScratch);  // [G + B] extended angle table
   unsigned short* s_perm = reinterpret_cast<unsigned short*>(s_relx + NXP);
   unsigned short* s_lut = s_perm + B;
@@ -205,6 +211,10 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
   double* s_ang = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(s_cls + NE) + 7) & ~(uintptr_t)7);   // [B0] beam angles, [D] heading angles (radians)
   unsigned short* s_member = reinterpret_cast<unsigned short*>(s_ang + (GRID ? P.g_B0 + P.g_D : 0));   // [NE] entries by class
   unsigned short* s_first = s_member + NE;                                                     // [B + 1] start of every class in s_member
+  // FAST (never together with GRID): the interval tables stand where the class tables would
+  float* s_ivedge = reinterpret_cast<float*>(s_cls);                                           // [IVN + 1]
+  unsigned short* s_ivbeam = reinterpret_cast<unsigned short*>(s_ivedge + IVN + 1);            // [B]
+  unsigned char* s_ivlut = reinterpret_cast<unsigned char*>(s_ivbeam + B);                     // [iv_NB]
 
   for (int k = threadIdx.x; k < B; k += blockDim.x) {
     s_ts[k] = P.tab_sorted[k];
@@ -228,6 +238,11 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
   }
   for (int k = threadIdx.x; k < NXP; k += blockDim.x) s_relx[k] = (k < P.G + B) ? P.relx[k] : 1.0e30f;  // padding: beyond any window
   for (int k = threadIdx.x; k < NB; k += blockDim.x) s_lut[k] = P.lut[k];
+  if (FAST && IVN > 0) {
+    for (int k = threadIdx.x; k <= IVN; k += blockDim.x) s_ivedge[k] = P.iv_edge[k];
+    for (int k = threadIdx.x; k < B; k += blockDim.x) s_ivbeam[k] = P.iv_beam[k];
+    for (int k = threadIdx.x; k < P.iv_NB; k += blockDim.x) s_ivlut[k] = P.iv_lut[k];
+  }
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
@@ -236,6 +251,9 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
   unsigned long long* const emin = rmin + NXP;                     // GRID: per entry, what only its own angle let in
   unsigned long long* const aux = s_aux_all + (size_t)wv * RS;     // STAGE: hit cell per entry; PRODUCT: p_k in caller order
   unsigned int* const ring = s_walk_all + (size_t)wv * kWaveScratch;   // [128] cells waiting to be matched
+  unsigned long long* const imin = s_imin_all + (size_t)wv * IVN;      // FAST: minima per sector interval
+  const float iv_originf = (float)P.iv_origin, iv_inv_bwf = (float)((double)P.iv_NB / kTwoPi), iv_th_hif = (float)P.iv_th_hi;
+  const float iv_nearf = (float)kEdgeEps + 3e-6f;     // closer than this to a sector edge, float32 does not decide
 
   const unsigned long long r2max_bits = (unsigned long long)__double_as_longlong(P.r2max);
   const float disk_r = (float)(P.z_max * (1.0 + 1e-5) + 0.02 * (P.res_x < P.res_y ? P.res_x : P.res_y));
@@ -273,6 +291,10 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
       rmin[k] = r2max_bits;
       if (STAGE) aux[k] = 0xffffffffull;
     }
+    // headings for which the reference's predicate is the circular one take the interval path (wave-uniform)
+    const bool use_iv = FAST && IVN > 0 && (float)th >= 0.0f && (float)th <= iv_th_hif;
+    if (use_iv)
+      for (int k = lane; k < IVN; k += 64) imin[k] = r2max_bits;
     // tile that holds the particle; poses far outside any map (or NaN) visit no tile
     // (a product instead of a division: an index off by one at an exact tile edge is covered by the
     // ring table's two cells of slack)
@@ -301,10 +323,29 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
       const double dx = ox - x, dy = oy - y;              // :124-125, float64
       const double r2 = dx * dx + dy * dy;                // :126
       COUNT(1);
-      if (valid && r2 <= P.r2max) {       // :127
+      bool hit = valid && r2 <= P.r2max;       // :127
+      const float aaf = bearing_f32((float)dy, (float)dx);
+      const unsigned long long r2bits = (unsigned long long)__double_as_longlong(r2);
+      if constexpr (FAST) {
+        if (use_iv) {
+          // the interval that holds the bearing: one minimum serves every beam whose sector spans it.  Only a
+          // bearing within rounding of a sector edge goes through the beam-by-beam test below.
+          float a = (aaf - thf) - iv_originf;
+          a += a < 0.0f ? 6.2831853071795865f : 0.0f;
+          a -= a >= 6.2831853071795865f ? 6.2831853071795865f : 0.0f;
+          int bkt = (int)(a * iv_inv_bwf);
+          bkt = bkt < 0 ? 0 : (bkt > P.iv_NB - 1 ? P.iv_NB - 1 : bkt);
+          int m = s_ivlut[bkt];
+          float e1 = s_ivedge[m + 1];
+          while (e1 <= a && m + 1 < IVN) { ++m; e1 = s_ivedge[m + 1]; }
+          const float e0 = s_ivedge[m];
+          const bool near_edge = !((a - e0 >= iv_nearf) && (e1 - a >= iv_nearf));   // also NaN
+          if (hit && !near_edge) atomicMin(&imin[m], r2bits);
+          hit = hit && near_edge;
+        }
+      }
+      if (hit) {
         COUNTL(2);
-        const float aaf = bearing_f32((float)dy, (float)dx);
-        const unsigned long long r2bits = (unsigned long long)__double_as_longlong(r2);
         const unsigned long long cellbits = (unsigned long long)((unsigned int)row * (unsigned int)P.W + (unsigned int)col);
         // beams whose table angle lies within `reach` of aa - th + c*2pi, c in {-1, 0, 1}
         double psi = 0.0;
@@ -570,7 +611,16 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
         return (double)(ex - 1023) + (double)__builtin_amdgcn_logf((float)mant);
       };
       for (int k = lane; k < B; k += 64) {
-        const unsigned long long rb = rmin[G + k];
+        unsigned long long rb = rmin[G + k];
+        if (use_iv) {                                                 // the intervals the beam's sector spans
+          const unsigned int span_k = s_ivbeam[k];
+          int m = (int)(span_k & 0xffu);
+          for (int j = (int)(span_k >> 8); j > 0; --j) {
+            const unsigned long long v = imin[m];
+            rb = v < rb ? v : rb;
+            m = m + 1 == IVN ? 0 : m + 1;
+          }
+        }
         const double r2 = __longlong_as_double((long long)rb);
         const float num = (float)(r2 - s_zt[k]);                      // z^2 - z*^2, cancellation exact in float64
         const float2 zf = reinterpret_cast<const float2*>(s_el)[k];   // z*, eta * lambda * w_short
@@ -703,7 +753,8 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
 #endif
 }
 
-static size_t ray_lds_bytes(int B, int G, int NB, bool aux, int waves = kWavesPerBlock, int NE = 0, int B0 = 0) {
+static size_t ray_lds_bytes(int B, int G, int NB, bool aux, int waves = kWavesPerBlock, int NE = 0, int B0 = 0, int iv_NE = 0,
+                            int iv_NB = 0) {
   const int NXP = B + G + kGroup;
   const int NT = NE ? B0 : B;
   size_t s = (size_t)(B + 2 * NT) * sizeof(double);
@@ -711,6 +762,10 @@ static size_t ray_lds_bytes(int B, int G, int NB, bool aux, int waves = kWavesPe
   s += (size_t)waves * kWaveScratch * sizeof(unsigned int);
   s += (size_t)NXP * sizeof(float);
   s += ((size_t)B + NB + 4) * sizeof(unsigned short);
+  if (iv_NE) {                                                                 // sector intervals (float32-mixture instantiation)
+    s += (size_t)waves * iv_NE * sizeof(unsigned long long);
+    s += (size_t)(iv_NE + 1) * sizeof(float) + (size_t)B * sizeof(unsigned short) + (size_t)iv_NB + 8;
+  }
   if (NE) {
     s += (size_t)NE * sizeof(unsigned int) + 8;                            // class / heading / beam of every entry (+ alignment of what follows)
     s += (size_t)(B0 + NE / B0) * sizeof(double);                          // beam and heading angles
@@ -766,7 +821,10 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
   P.rn_sigma = rn_sigma; P.rn_seed = rn_seed;
   const bool device_noise = rn_sigma > 0.0;
   const bool stage = ranges_out != nullptr;
-  const size_t lds = ray_lds_bytes(P.B, P.G, P.NB, stage || product);
+  // log-weights only, float32 state, no range noise, measured ranges finite and >= 0: the float32 mixture
+  const bool fast = !stage && !device_noise && dtype == MCLHIP_F32 && !product && !range_noise && c->zmeas_ok && MCL_FAST_LIKELIHOOD;
+  if (!fast || !MCL_FAST_INTERVALS) P.iv_NE = 0;
+  const size_t lds = ray_lds_bytes(P.B, P.G, P.NB, stage || product, kWavesPerBlock, 0, 0, P.iv_NE, P.iv_NB);
   if (lds > 160 * 1024) return fail(c, MCLHIP_E_LIMIT, "beam table does not fit the kernel's LDS budget");
   int64_t blocks = (n + kWavesPerBlock - 1) / kWavesPerBlock;
   const int64_t max_blocks = MCL_MAX_BLOCKS;
@@ -794,8 +852,6 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
       if (product) MCL_RAY_N(double, false, true, true); else MCL_RAY_N(double, false, false, true);
     }
   } else if (dtype == MCLHIP_F32) {
-    // log-weights only, no range noise, measured ranges finite and >= 0: the float32 mixture
-    const bool fast = !product && !range_noise && c->zmeas_ok && MCL_FAST_LIKELIHOOD;
     if (product) MCL_RAY(float, false, true);
     else if (fast) MCL_RAY_F(float, false, false, false, true);
     else MCL_RAY(float, false, false);
