@@ -202,7 +202,8 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
   // FAST: per wave, the smallest squared distance per sector interval (see RayParams::iv_*)
   const int IVN = FAST ? P.iv_NE : 0;
   unsigned long long* s_imin_all = s_aux_all + (size_t)((STAGE || PRODUCT) ? WPB * RS : 0);
-  unsigned int* s_walk_all = reinterpret_cast<unsigned int*>(s_imin_all + (size_t)WPB * IVN);
+  const int IVS = FAST ? P.iv_NE + P.iv_cmax : 0;   // per wave: the minima, then the first iv_cmax again (a sector that wraps reads on)
+  unsigned int* s_walk_all = reinterpret_cast<unsigned int*>(s_imin_all + (size_t)WPB * IVS);
   float* s_relx = reinterpret_cast<float*>(s_walk_all + (size_t)WPB * kWaveScratch);  // [G + B] extended angle table
   unsigned short* s_perm = reinterpret_cast<unsigned short*>(s_relx + NXP);
   unsigned short* s_lut = s_perm + B;
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
   unsigned long long* const emin = rmin + NXP;                     // GRID: per entry, what only its own angle let in
   unsigned long long* const aux = s_aux_all + (size_t)wv * RS;     // STAGE: hit cell per entry; PRODUCT: p_k in caller order
   unsigned int* const ring = s_walk_all + (size_t)wv * kWaveScratch;   // [128] cells waiting to be matched
-  unsigned long long* const imin = s_imin_all + (size_t)wv * IVN;      // FAST: minima per sector interval
+  unsigned long long* const imin = s_imin_all + (size_t)wv * IVS;      // FAST: minima per sector interval
   const float iv_originf = (float)P.iv_origin, iv_inv_bwf = (float)((double)P.iv_NB / kTwoPi), iv_th_hif = (float)P.iv_th_hi;
   const float iv_nearf = (float)kEdgeEps + 3e-6f;     // closer than this to a sector edge, float32 does not decide
 
@@ -335,10 +336,12 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
           a -= a >= 6.2831853071795865f ? 6.2831853071795865f : 0.0f;
           int bkt = (int)(a * iv_inv_bwf);
           bkt = bkt < 0 ? 0 : (bkt > P.iv_NB - 1 ? P.iv_NB - 1 : bkt);
-          int m = s_ivlut[bkt];
-          float e1 = s_ivedge[m + 1];
-          while (e1 <= a && m + 1 < IVN) { ++m; e1 = s_ivedge[m + 1]; }
-          const float e0 = s_ivedge[m];
+          int m = s_ivlut[bkt];                 // a bucket is a quarter of the average interval: at most one step as a rule
+          float e0 = s_ivedge[m], e1 = s_ivedge[m + 1];
+          if (e1 <= a && m + 1 < IVN) {
+            ++m; e0 = e1; e1 = s_ivedge[m + 1];
+            while (e1 <= a && m + 1 < IVN) { ++m; e0 = e1; e1 = s_ivedge[m + 1]; }
+          }
           const bool near_edge = !((a - e0 >= iv_nearf) && (e1 - a >= iv_nearf));   // also NaN
           if (hit && !near_edge) atomicMin(&imin[m], r2bits);
           hit = hit && near_edge;
@@ -507,6 +510,10 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
 
     // ranges -> beam mixture -> weight
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (use_iv) {
+      for (int k = lane; k < P.iv_cmax; k += 64) imin[IVN + k] = imin[k];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
     if (p + stride < n) {   // next pose in flight while this particle's weight is computed
       nx = xs[p + stride]; ny = ys[p + stride]; nth = ths[p + stride];
       if (!STAGE && !GRID) npm = pm[p + stride];
@@ -612,14 +619,18 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
       };
       for (int k = lane; k < B; k += 64) {
         unsigned long long rb = rmin[G + k];
-        if (use_iv) {                                                 // the intervals the beam's sector spans
+        if (use_iv) {
+          // the intervals the beam's sector spans (squared distances are not negative: their order as float64 is their
+          // order as bit patterns)
           const unsigned int span_k = s_ivbeam[k];
-          int m = (int)(span_k & 0xffu);
-          for (int j = (int)(span_k >> 8); j > 0; --j) {
-            const unsigned long long v = imin[m];
-            rb = v < rb ? v : rb;
-            m = m + 1 == IVN ? 0 : m + 1;
+          const unsigned long long* run = imin + (span_k & 0xffu);
+          const int cnt = (int)(span_k >> 8);
+          double best = __longlong_as_double((long long)rb);
+          for (int j = 0; j < P.iv_cmax; ++j) {
+            const double v = __longlong_as_double((long long)run[j]);
+            best = fmin(best, j < cnt ? v : best);
           }
+          rb = (unsigned long long)__double_as_longlong(best);
         }
         const double r2 = __longlong_as_double((long long)rb);
         const float num = (float)(r2 - s_zt[k]);                      // z^2 - z*^2, cancellation exact in float64
@@ -754,7 +765,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
 }
 
 static size_t ray_lds_bytes(int B, int G, int NB, bool aux, int waves = kWavesPerBlock, int NE = 0, int B0 = 0, int iv_NE = 0,
-                            int iv_NB = 0) {
+                            int iv_NB = 0, int iv_cmax = 0) {
   const int NXP = B + G + kGroup;
   const int NT = NE ? B0 : B;
   size_t s = (size_t)(B + 2 * NT) * sizeof(double);
@@ -763,7 +774,7 @@ static size_t ray_lds_bytes(int B, int G, int NB, bool aux, int waves = kWavesPe
   s += (size_t)NXP * sizeof(float);
   s += ((size_t)B + NB + 4) * sizeof(unsigned short);
   if (iv_NE) {                                                                 // sector intervals (float32-mixture instantiation)
-    s += (size_t)waves * iv_NE * sizeof(unsigned long long);
+    s += (size_t)waves * (iv_NE + iv_cmax) * sizeof(unsigned long long);
     s += (size_t)(iv_NE + 1) * sizeof(float) + (size_t)B * sizeof(unsigned short) + (size_t)iv_NB + 8;
   }
   if (NE) {
@@ -823,8 +834,8 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
   const bool stage = ranges_out != nullptr;
   // log-weights only, float32 state, no range noise, measured ranges finite and >= 0: the float32 mixture
   const bool fast = !stage && !device_noise && dtype == MCLHIP_F32 && !product && !range_noise && c->zmeas_ok && MCL_FAST_LIKELIHOOD;
-  if (!fast || !MCL_FAST_INTERVALS) P.iv_NE = 0;
-  const size_t lds = ray_lds_bytes(P.B, P.G, P.NB, stage || product, kWavesPerBlock, 0, 0, P.iv_NE, P.iv_NB);
+  if (!fast || !MCL_FAST_INTERVALS) { P.iv_NE = 0; P.iv_cmax = 0; }
+  const size_t lds = ray_lds_bytes(P.B, P.G, P.NB, stage || product, kWavesPerBlock, 0, 0, P.iv_NE, P.iv_NB, P.iv_cmax);
   if (lds > 160 * 1024) return fail(c, MCLHIP_E_LIMIT, "beam table does not fit the kernel's LDS budget");
   int64_t blocks = (n + kWavesPerBlock - 1) / kWavesPerBlock;
   const int64_t max_blocks = MCL_MAX_BLOCKS;
