@@ -80,7 +80,7 @@ RayParams make_ray_params(const mclhip_ctx* c) {
   P.tab_sorted = c->tab_sorted; P.perm = c->perm; P.lut = c->lut;
   P.ts_min = c->ts_min; P.ts_max = c->ts_max; P.inv_bw = c->inv_bw;
   P.relx = c->relx; P.G = c->G; P.ext_min = c->ext_min;
-  P.iv_NE = c->iv_NE; P.iv_NB = c->iv_NB; P.iv_cmax = c->iv_cmax; P.iv_edge = c->iv_edge; P.iv_beam = c->iv_beam; P.iv_lut = c->iv_lut;
+  P.iv_NE = c->iv_NE; P.iv_NB = c->iv_NB; P.iv_cmax = c->iv_cmax; P.iv_cmin = c->iv_cmin; P.iv_edge = c->iv_edge; P.iv_beam = c->iv_beam; P.iv_lut = c->iv_lut;
   P.iv_origin = c->iv_origin; P.iv_th_hi = c->iv_th_hi;
   P.half = c->half;
   P.two_pi_lo = M_PI * 2 - c->half;  // mc_localization.py:149
@@ -496,7 +496,7 @@ int mcl::set_sensor_table(mclhip_ctx* c, const double* tab_rad, int B, double z_
   {
     // Sector intervals.  Available when every beam angle lies in [0, 2 pi) and the sectors are proper arcs; edges that
     // agree to 1e-9 rad count as one (a bearing that close to either is decided by the exact test anyway).
-    c->iv_NE = 0; c->iv_NB = 0; c->iv_cmax = 0;
+    c->iv_NE = 0; c->iv_NB = 0; c->iv_cmax = 0; c->iv_cmin = 0;
     const bool usable = c->ts_min >= 0.0 && c->ts_max < two_pi && half > 16.0 * kEdgeEps && half < 0.5 * M_PI;
     if (usable) {
       const double origin = c->ts_min - half;
@@ -519,12 +519,12 @@ int mcl::set_sensor_table(mclhip_ctx* c, const double* tab_rad, int B, double z_
       };
       bool ok = NE >= 2 && NE <= 255 && edge[0] <= 1e-9;
       std::vector<uint16_t> beam(B);
-      int cmax = 0;
+      int cmax = 0, cmin = 1 << 30;
       for (int k = 0; k < B && ok; ++k) {
         const int m0 = index_of(reduced(ts[k] - half)), m1 = index_of(reduced(ts[k] + half));
         const int cnt = (m1 - m0 + NE) % NE;
         if (cnt < 1 || cnt > 255) ok = false;
-        cmax = std::max(cmax, cnt);
+        cmax = std::max(cmax, cnt); cmin = std::min(cmin, cnt);
         beam[k] = (uint16_t)(m0 | (cnt << 8));
       }
       if (ok) {
@@ -547,7 +547,7 @@ int mcl::set_sensor_table(mclhip_ctx* c, const double* tab_rad, int B, double z_
         MCL_HIP(c, hipMemcpy(c->iv_edge, ef.data(), ef.size() * sizeof(float), hipMemcpyHostToDevice));
         MCL_HIP(c, hipMemcpy(c->iv_beam, beam.data(), B * sizeof(uint16_t), hipMemcpyHostToDevice));
         MCL_HIP(c, hipMemcpy(c->iv_lut, ilut.data(), NBI, hipMemcpyHostToDevice));
-        c->iv_NE = NE; c->iv_NB = NBI; c->iv_cmax = cmax; c->iv_origin = origin;
+        c->iv_NE = NE; c->iv_NB = NBI; c->iv_cmax = cmax; c->iv_cmin = cmin; c->iv_origin = origin;
         c->iv_th_hi = two_pi - 2.0 * half - 1e-3;
       }
     }

@@ -55,7 +55,7 @@ struct RayParams {
   // A cell that is not within rounding of an edge then costs ONE minimum (its interval's) instead of one per beam, and
   // a beam's range is the smallest of the few intervals its sector spans.  iv_NE == 0: not available for this table.
   int iv_NE, iv_NB;            // intervals (<= 255), buckets of the look-up (a power of two)
-  int iv_cmax;                 // most intervals a sector spans
+  int iv_cmax, iv_cmin;        // most / fewest intervals a sector spans
   const float* iv_edge;        // [NE + 1] lower edge of every interval, measured from iv_origin; iv_edge[NE] = 2 pi
   const uint16_t* iv_beam;     // [B] first interval | number of intervals << 8 of the beam at sorted position k
   const uint8_t* iv_lut;       // [NB] bucket -> last interval that starts at or below the bucket's lower edge
@@ -134,7 +134,7 @@ struct mclhip_ctx {
   uint16_t* inv_perm = nullptr;
   uint16_t* lut = nullptr;
   float* iv_edge = nullptr; uint16_t* iv_beam = nullptr; uint8_t* iv_lut = nullptr;   // sector intervals (see RayParams)
-  int iv_NE = 0, iv_NB = 0, iv_cmax = 0; double iv_origin = 0.0, iv_th_hi = 0.0;
+  int iv_NE = 0, iv_NB = 0, iv_cmax = 0, iv_cmin = 0; double iv_origin = 0.0, iv_th_hi = 0.0;
   float* relx = nullptr;
   int G = 0;
   double ext_min = 0;

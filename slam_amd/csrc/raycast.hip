@@ -626,9 +626,15 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
           const unsigned long long* run = imin + (span_k & 0xffu);
           const int cnt = (int)(span_k >> 8);
           double best = __longlong_as_double((long long)rb);
-          for (int j = 0; j < P.iv_cmax; ++j) {
-            const double v = __longlong_as_double((long long)run[j]);
-            best = fmin(best, j < cnt ? v : best);
+          // (the plain instruction: nothing here is a NaN, so the library minimum's quieting of operands is not needed)
+          auto lower = [](double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+          if (P.iv_cmin == P.iv_cmax) {                               // every sector spans as many intervals (evenly spaced beams)
+            for (int j = 0; j < P.iv_cmax; ++j) best = lower(best, __longlong_as_double((long long)run[j]));
+          } else {
+            for (int j = 0; j < P.iv_cmax; ++j) {
+              const double v = __longlong_as_double((long long)run[j]);
+              best = lower(best, j < cnt ? v : best);
+            }
           }
           rb = (unsigned long long)__double_as_longlong(best);
         }
