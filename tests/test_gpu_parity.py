@@ -255,6 +255,60 @@ def test_f32_state_mode(name):
     assert np.max(np.abs(logw3[fin] - lwn[fin]) / np.maximum(1.0, np.abs(lwn[fin]))) < 1e-5
 
 
+@pytest.mark.parametrize("beams", ["even180", "even360", "reference13", "uneven"])
+def test_sector_intervals_against_the_oracle(beams):
+    """The float32 instantiation files a cell under the sector interval its bearing falls in (one minimum per interval,
+    a beam's range = the smallest of the intervals its sector spans) when the heading lies in [0, 2 pi - 2 half-angles);
+    other headings, and bearings within rounding of a sector edge, go beam by beam.  Headings on both sides of the two
+    limits, negative ones and ones past a full turn, evenly and unevenly spaced beam sets (overlapping sectors, disjoint
+    sectors, sectors that share an edge): log-weights against the oracle's, which follows mc_localization.py:116-171."""
+    from slam_amd import workload as W
+    L = _lib()
+    grid = W.synthetic_map(256)
+    if beams == "even180":
+        angles = W.beam_angles(180)
+    elif beams == "even360":
+        angles = W.beam_angles(360)
+    elif beams == "reference13":
+        angles = [0, 15, 30, 45, 60, 75, 90, 345, 330, 315, 300, 285, 270]           # mc_localization.py:45
+    else:
+        angles = [0.0, 3.0, 4.5, 10.0, 20.0, 20.5, 77.7, 180.0, 181.0, 190.0, 200.0, 269.9, 275.0, 359.0]   # 10 and 20: a shared edge
+    half = 5 * np.pi / 180.0
+    rng = np.random.RandomState(5)
+    M = 1500
+    X = W.uniform_particles(grid, M, seed=3)
+    th = rng.uniform(0.0, 2 * np.pi, M)
+    lim = 2 * np.pi - 2 * half - 1e-3
+    th[:200] = lim + rng.uniform(-2e-3, 2e-3, 200)            # around the upper limit of the interval path
+    th[200:400] = rng.uniform(-1e-3, 1e-3, 200)               # around zero
+    th[400:500] = rng.uniform(-7.0, 0.0, 100)                 # negative, some below one turn
+    th[500:600] = rng.uniform(2 * np.pi, 13.5, 100)           # past one and two turns
+    th[600:700] = np.round(rng.uniform(0, 72, 100)) * (5 * np.pi / 180.0)   # sector edges on lattice directions
+    X[:, 2] = th
+    X = X.astype(np.float32).astype(np.float64)               # what a float32 state holds
+    ctx = L.Context(0, L.F32)
+    ctx.set_map(grid, W.RES, W.RES)
+    w4 = np.array([0.97, 0.005, 0.020, 0.005]); w4 /= w4.sum()
+    ctx.set_sensor(angles, W.Z_MAX, 0.15, 1.0, w4, half)
+    z_meas = ctx.raycast(np.array([3.0, 4.5, 0.3]), want_hits=False)[0][0]
+    ctx.set_particles(X)
+    zero = np.zeros((M, 3, 12), np.int16)
+    ctx.shard_sample(0.0, 1e-12, 0.1, ALPHA, z_meas, zero, 0, L.W_LOG)     # no motion: the poses stay what they are
+    Xd, _, logw = ctx.get_particles(True, False, True)
+    lut, cell = O.obstacle_lut(grid)
+    Ro, _ = O.sector_query_batch(Xd, lut, cell, angles)
+    _, lwo, _ = O.weights_from_ranges(Ro, z_meas, O.free_cell(Xd[:, 0], Xd[:, 1], grid), O.SensorParams())
+    fin = np.isfinite(lwo)
+    assert np.array_equal(np.isfinite(logw), fin) and fin.sum() > 0.8 * M
+    err = np.abs(logw[fin] - lwo[fin]) / np.maximum(1.0, np.abs(lwo[fin]))
+    # an obstacle centre whose bearing sits on a sector edge to the last bit is in or out by atan2's last bit (libm's
+    # against the device's): lattice headings produce such ties, everything else must agree
+    tie = np.zeros(M, bool); tie[600:700] = True
+    assert err[~tie[fin]].max() < 1e-5, (beams, err[~tie[fin]].max())
+    assert np.mean(err[tie[fin]] < 1e-5) > 0.9
+    ctx.close()
+
+
 def test_dropin_class_follows_reference_run():
     """The drop-in class driven like the reference's __main__ (mc_localization.py:303-331) under
     the same np.random seed: same initial cloud, same indices, same trajectory."""
