@@ -255,7 +255,7 @@ def test_f32_state_mode(name):
     assert np.max(np.abs(logw3[fin] - lwn[fin]) / np.maximum(1.0, np.abs(lwn[fin]))) < 1e-5
 
 
-@pytest.mark.parametrize("beams", ["even180", "even360", "reference13", "uneven"])
+@pytest.mark.parametrize("beams", ["even180", "even360", "reference13", "uneven", "wide_repeated", "narrow", "single"])
 def test_sector_intervals_against_the_oracle(beams):
     """The float32 instantiation files a cell under the sector interval its bearing falls in (one minimum per interval,
     a beam's range = the smallest of the intervals its sector spans) when the heading lies in [0, 2 pi - 2 half-angles);
@@ -271,9 +271,15 @@ def test_sector_intervals_against_the_oracle(beams):
         angles = W.beam_angles(360)
     elif beams == "reference13":
         angles = [0, 15, 30, 45, 60, 75, 90, 345, 330, 315, 300, 285, 270]           # mc_localization.py:45
-    else:
+    elif beams == "uneven":
         angles = [0.0, 3.0, 4.5, 10.0, 20.0, 20.5, 77.7, 180.0, 181.0, 190.0, 200.0, 269.9, 275.0, 359.0]   # 10 and 20: a shared edge
-    half = 5 * np.pi / 180.0
+    elif beams == "wide_repeated":
+        angles = [0.0, 0.0, 10.0, 100.0, 100.0, 100.0, 185.0, 359.0, 40.0]           # 30-degree sectors, beams given twice
+    elif beams == "narrow":
+        angles = [k * 7.5 for k in range(48)]                                        # 1-degree sectors, gaps between them
+    else:
+        angles = [123.0]
+    half = {"wide_repeated": 30.0, "narrow": 1.0}.get(beams, 5.0) * np.pi / 180.0
     rng = np.random.RandomState(5)
     M = 1500
     X = W.uniform_particles(grid, M, seed=3)
@@ -296,7 +302,7 @@ def test_sector_intervals_against_the_oracle(beams):
     ctx.shard_sample(0.0, 1e-12, 0.1, ALPHA, z_meas, zero, 0, L.W_LOG)     # no motion: the poses stay what they are
     Xd, _, logw = ctx.get_particles(True, False, True)
     lut, cell = O.obstacle_lut(grid)
-    Ro, _ = O.sector_query_batch(Xd, lut, cell, angles)
+    Ro, _ = O.sector_query_batch(Xd, lut, cell, angles, half_angle=half)
     _, lwo, _ = O.weights_from_ranges(Ro, z_meas, O.free_cell(Xd[:, 0], Xd[:, 1], grid), O.SensorParams())
     fin = np.isfinite(lwo)
     assert np.array_equal(np.isfinite(logw), fin) and fin.sum() > 0.8 * M
