@@ -279,7 +279,8 @@ def main():
     r_draw = rs.rand(n_total) / (M * world)
     alpha = [4, 2, 4, 4, 4, 2]
     filt = ShardedFilter(ctx, dist, rank, world, M, force_collectives=a.rehearse_collectives,
-                         device_path=False if a.host_collectives else None)
+                         device_path=False if a.host_collectives else (True if (dist is not None and a.backend == "gloo"
+                                                                                    and world > 1) else None))
 
     def one_step(t):
         if a.regime == "global":

@@ -156,7 +156,19 @@ def sequential_sum(values):
 
 
 def drive_exchanges(gen, torch, dist, stream):
-    """Serve the exchanges a device-step generator asks for with torch.distributed, on the step's stream."""
+    """Serve the exchanges a device-step generator asks for with torch.distributed, on the step's stream.  Under RCCL
+    the collectives read and write the device tensors; under gloo (ranks that share one GPU, in tests) the same calls
+    run on host copies."""
+    staged = dist.get_backend() != "nccl"
+
+    def gather(out, inp):
+        if staged:
+            host = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(host, inp.cpu())
+            out.copy_(host)
+        else:
+            dist.all_gather_into_tensor(out, inp)
+
     with torch.cuda.stream(stream):
         try:
             req = next(gen)
@@ -164,17 +176,27 @@ def drive_exchanges(gen, torch, dist, stream):
                 op = req[0]
                 val = None
                 if op == "all_reduce_max":
-                    dist.all_reduce(req[1], op=dist.ReduceOp.MAX)
+                    if staged:
+                        host = req[1].cpu()
+                        dist.all_reduce(host, op=dist.ReduceOp.MAX)
+                        req[1].copy_(host)
+                    else:
+                        dist.all_reduce(req[1], op=dist.ReduceOp.MAX)
                 elif op == "all_gather":
-                    dist.all_gather_into_tensor(req[1], req[2])
+                    gather(req[1], req[2])
                 elif op == "all_gather_read":
-                    dist.all_gather_into_tensor(req[1], req[2])
+                    gather(req[1], req[2])
                     val = req[1].cpu().numpy()
                 elif op == "all_to_all":
                     send, sc, rc = req[1], req[2], req[3]
-                    val = torch.empty((max(int(sum(rc)), 1), send.shape[1]), dtype=send.dtype, device=send.device)
-                    dist.all_to_all_single(val[:int(sum(rc))], send[:int(sum(sc))], [int(c) for c in rc],
-                                           [int(c) for c in sc])
+                    n_in, n_out = int(sum(sc)), int(sum(rc))
+                    val = torch.empty((max(n_out, 1), send.shape[1]), dtype=send.dtype, device=send.device)
+                    if staged:
+                        host = torch.empty((n_out, send.shape[1]), dtype=send.dtype)
+                        dist.all_to_all_single(host, send[:n_in].cpu(), [int(c) for c in rc], [int(c) for c in sc])
+                        val[:n_out].copy_(host)
+                    else:
+                        dist.all_to_all_single(val[:n_out], send[:n_in], [int(c) for c in rc], [int(c) for c in sc])
                 req = gen.send(val)
         except StopIteration as done:
             return done.value
@@ -208,7 +230,8 @@ class ShardedFilter:
                                isinstance(self.b, HipShardBackend))
             self.device_path = bool(device_path)
             if self.device_path:
-                self._device_setup(self.coll.torch, self.coll.dev)
+                torch = self.coll.torch      # (the step's tensors live on the GPU whatever carries the collectives)
+                self._device_setup(torch, torch.device("cuda", torch.cuda.current_device()))
         else:
             self.sizes, self.firsts, self.m_total = [self.m_local], [0, self.m_local], self.m_local
             self.device_path = False
@@ -390,7 +413,8 @@ class ShardedFastSLAM:
             device_path = self.coll.backend == "nccl"
         self.device_path = bool(device_path)
         if self.device_path:
-            self._device_setup(self.coll.torch, self.coll.dev)
+            torch = self.coll.torch
+            self._device_setup(torch, torch.device("cuda", torch.cuda.current_device()))
 
     @classmethod
     def for_layout(cls, ctx, rank, sizes, capacity):

@@ -33,18 +33,43 @@ def _inputs(M):
     return X, noise, rng.rand() / M
 
 
-def _rank_fn(rank, world, dist, sizes, dtype, mode, z_meas, use_device_noise):
+def _rank_fn(rank, world, dist, sizes, dtype, mode, z_meas, use_device_noise, device_path=None):
     from slam_amd.sharded import ShardedFilter
+    if device_path:
+        import torch
+        torch.cuda.set_device(0)
     M = sum(sizes)
     X, noise, r = _inputs(M)
     first = sum(sizes[:rank])
     sl = slice(first, first + sizes[rank])
     ctx = _setup(dtype)
     ctx.set_particles(X[sl])
-    f = ShardedFilter(ctx, dist, rank, world, sizes[rank], weight_mode=mode)
+    f = ShardedFilter(ctx, dist, rank, world, sizes[rank], weight_mode=mode, device_path=device_path)
+    assert f.device_path == bool(device_path)
     f.step(1.5, 0.0, 0.1, ALPHA, z_meas, r, seed=99, noise_ints=None if use_device_noise else noise[sl], want_idx=True)
     Xo, wo, _ = ctx.get_particles()
     return {"idx": f.last_idx, "X": Xo, "w": wo, "total": f.total}
+
+
+@pytest.mark.parametrize("sizes,devnoise", [((16384, 8192), False), ((8192, 8192, 11000), True)])
+def test_device_driven_step_between_processes_equals_one_context(sizes, devnoise):
+    """The device-driven step between real processes (one per rank, sharing the box's GPU; gloo carries the
+    collectives on host copies of the device tensors): the calls torch.distributed gets -- gathered tensors, split
+    sizes of the all-to-all -- are the ones an RCCL run makes.  Bit-equal to one context."""
+    from slam_amd import _lib
+    M = sum(sizes)
+    X, noise, r = _inputs(M)
+    ref = _setup(_lib.F32)
+    z_meas = ref.raycast(np.array([3.0, 4.5, 0.0]), want_hits=False)[0][0]
+    ref.set_particles(X)
+    ref.shard_sample(1.5, 0.0, 0.1, ALPHA, z_meas, None if devnoise else noise, 99, _lib.W_LOG)
+    ref.normalise(_lib.W_LOG)
+    idx = ref.resample(r, _lib.RESAMPLE_PARALLEL)
+    Xr, wr, _ = ref.get_particles()
+    res = run_ranks(_rank_fn, len(sizes), sizes, _lib.F32, _lib.W_LOG, z_meas, devnoise, True)
+    assert np.array_equal(np.concatenate([x["idx"] for x in res]), idx)
+    assert np.array_equal(np.concatenate([x["X"] for x in res]), Xr)
+    assert np.array_equal(np.concatenate([x["w"] for x in res]), wr)
 
 
 @pytest.mark.parametrize("sizes,dtype,mode,devnoise", [((16384, 8192), 1, 1, False), ((8192, 8192), 1, 0, False),
@@ -260,15 +285,19 @@ def _fs_inputs(M, steps):
     return out
 
 
-def _fs_rank_fn(rank, world, dist, sizes, steps):
+def _fs_rank_fn(rank, world, dist, sizes, steps, device_path=None):
     from oracle import fastslam_oracle as F
     from slam_amd import _lib
     from slam_amd.sharded import ShardedFastSLAM
+    if device_path:
+        import torch
+        torch.cuda.set_device(0)
     M = sum(sizes)
     first = sum(sizes[:rank])
     sl = slice(first, first + sizes[rank])
     ctx = _lib.Context(0, _lib.F64)
-    f = ShardedFastSLAM(ctx, dist, rank, world, sizes[rank], 16)
+    f = ShardedFastSLAM(ctx, dist, rank, world, sizes[rank], 16, device_path=device_path)
+    assert f.device_path == bool(device_path)
     idx = []
     for (ut, tr, tp, tv, ints, nrm, r) in _fs_inputs(M, steps):
         f.step(ut[0], ut[1], F.DT, F.ALPHA, tr, tp, tv, ints[sl], nrm[sl], r, want_idx=True)
@@ -278,8 +307,8 @@ def _fs_rank_fn(rank, world, dist, sizes, steps):
     return st
 
 
-@pytest.mark.parametrize("sizes", [(8192, 8192), (8192, 8192, 3000)])
-def test_fastslam_over_ranks_equals_one_context(sizes):
+@pytest.mark.parametrize("sizes,device_path", [((8192, 8192), None), ((8192, 8192, 3000), None), ((8192, 8192, 3000), True)])
+def test_fastslam_over_ranks_equals_one_context(sizes, device_path):
     """FastSLAM with the particles split over ranks (gloo carries the exchanges, the ranks share the
     box's GPU): ancestors and the whole particle state, feature slots included, equal the
     single-context filter bit for bit after four steps."""
@@ -292,7 +321,7 @@ def test_fastslam_over_ranks_equals_one_context(sizes):
     for (ut, tr, tp, tv, ints, nrm, r) in _fs_inputs(M, steps):
         ref_idx.append(ref.fs_step(ut[0], ut[1], F.DT, F.ALPHA, tr, tp, tv, ints, nrm, r, want_idx=True))
     want = ref.fs_get_state()
-    res = run_ranks(_fs_rank_fn, len(sizes), sizes, steps)
+    res = run_ranks(_fs_rank_fn, len(sizes), sizes, steps, device_path)
     for t in range(steps):
         assert np.array_equal(np.concatenate([x["idx"][t] for x in res]), ref_idx[t]), t
     for k in ("pose", "w", "nfeat", "new_id", "f_m", "f_cov", "f_i", "f_w", "f_id"):
