@@ -63,4 +63,8 @@ def test_two_ranks_on_one_gpu_through_the_launcher():
     assert len(lines) == 1, out
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["world_size_seen"] == 2 and d["value"] > 0
-    assert "host-combined" in d["config"]["sharding"]
+    assert "device-driven" in d["config"]["sharding"] and d["exchange"]["host_reads_per_step"] == 1
+    rc, out, err = _run(["--gpus", "2", "--backend", "gloo", "--share-gpu", "--host-collectives"] + SMALL)
+    assert rc == 0, err[-2000:]
+    d = json.loads([x for x in out.splitlines() if x.strip()][0])
+    assert d["n_gpus"] == 2 and "host-combined" in d["config"]["sharding"]
