@@ -159,7 +159,7 @@ __device__ __attribute__((noinline)) double slow_log(double v) { return log(v); 
 // The float32-mixture instantiation needs fewer registers: seven waves per SIMD (72 VGPRs).  Measured at 2^20 x 180:
 // 5 waves 1.51 ms, 6 waves 1.43 ms, 7 waves 1.40 ms, 8 waves 1.74 ms.
 #ifndef MCL_FAST_INTERVALS
-#define MCL_FAST_INTERVALS 1
+#define MCL_FAST_INTERVALS 1      // sector intervals in every instantiation but the staged query and the histogram filter
 #endif
 #ifndef MCL_FAST_WAVES
 #define MCL_FAST_WAVES 7
@@ -199,10 +199,12 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
   const int NXP = P.G + B + kGroup;                              // extended table + one group of padding
   const int RS = NXP + NE + (GRID ? B : 0);                      // per wave: minima per table entry, then (GRID) per entry, and a double per class
   unsigned long long* s_aux_all = s_rmin_all + (size_t)WPB * RS;
-  // FAST: per wave, the smallest squared distance per sector interval (see RayParams::iv_*)
-  const int IVN = FAST ? P.iv_NE : 0;
+  // per wave, the smallest squared distance per sector interval (see RayParams::iv_*); not for the staged query
+  // (which also wants the hit cell) nor for the histogram filter's classes
+  constexpr bool IVK = !STAGE && !GRID;
+  const int IVN = IVK ? P.iv_NE : 0;
   unsigned long long* s_imin_all = s_aux_all + (size_t)((STAGE || PRODUCT) ? WPB * RS : 0);
-  const int IVS = FAST ? P.iv_NE + P.iv_cmax : 0;   // per wave: the minima, then the first iv_cmax again (a sector that wraps reads on)
+  const int IVS = IVK ? P.iv_NE + P.iv_cmax : 0;   // per wave: the minima, then the first iv_cmax again (a sector that wraps reads on)
   unsigned int* s_walk_all = reinterpret_cast<unsigned int*>(s_imin_all + (size_t)WPB * IVS);
   float* s_relx = reinterpret_cast<float*>(s_walk_all + (size_t)WPB * kWaveScratch);  // [G + B] extended angle table
   unsigned short* s_perm = reinterpret_cast<unsigned short*>(s_relx + NXP);
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
   double* s_ang = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(s_cls + NE) + 7) & ~(uintptr_t)7);   // [B0] beam angles, [D] heading angles (radians)
   unsigned short* s_member = reinterpret_cast<unsigned short*>(s_ang + (GRID ? P.g_B0 + P.g_D : 0));   // [NE] entries by class
   unsigned short* s_first = s_member + NE;                                                     // [B + 1] start of every class in s_member
-  // FAST (never together with GRID): the interval tables stand where the class tables would
+  // the interval tables (never together with GRID) stand where the class tables would
   float* s_ivedge = reinterpret_cast<float*>(s_cls);                                           // [IVN + 1]
   unsigned short* s_ivbeam = reinterpret_cast<unsigned short*>(s_ivedge + IVN + 1);            // [B]
   unsigned char* s_ivlut = reinterpret_cast<unsigned char*>(s_ivbeam + B);                     // [iv_NB]
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
   }
   for (int k = threadIdx.x; k < NXP; k += blockDim.x) s_relx[k] = (k < P.G + B) ? P.relx[k] : 1.0e30f;  // padding: beyond any window
   for (int k = threadIdx.x; k < NB; k += blockDim.x) s_lut[k] = P.lut[k];
-  if (FAST && IVN > 0) {
+  if (IVK && IVN > 0) {
     for (int k = threadIdx.x; k <= IVN; k += blockDim.x) s_ivedge[k] = P.iv_edge[k];
     for (int k = threadIdx.x; k < B; k += blockDim.x) s_ivbeam[k] = P.iv_beam[k];
     for (int k = threadIdx.x; k < P.iv_NB; k += blockDim.x) s_ivlut[k] = P.iv_lut[k];
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
   unsigned long long* const emin = rmin + NXP;                     // GRID: per entry, what only its own angle let in
   unsigned long long* const aux = s_aux_all + (size_t)wv * RS;     // STAGE: hit cell per entry; PRODUCT: p_k in caller order
   unsigned int* const ring = s_walk_all + (size_t)wv * kWaveScratch;   // [128] cells waiting to be matched
-  unsigned long long* const imin = s_imin_all + (size_t)wv * IVS;      // FAST: minima per sector interval
+  unsigned long long* const imin = s_imin_all + (size_t)wv * IVS;      // minima per sector interval
   const float iv_originf = (float)P.iv_origin, iv_inv_bwf = (float)((double)P.iv_NB / kTwoPi), iv_th_hif = (float)P.iv_th_hi;
   const float iv_nearf = (float)kEdgeEps + 3e-6f;     // closer than this to a sector edge, float32 does not decide
 
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
       if (STAGE) aux[k] = 0xffffffffull;
     }
     // headings for which the reference's predicate is the circular one take the interval path (wave-uniform)
-    const bool use_iv = FAST && IVN > 0 && (float)th >= 0.0f && (float)th <= iv_th_hif;
+    const bool use_iv = IVK && IVN > 0 && (float)th >= 0.0f && (float)th <= iv_th_hif;
     if (use_iv)
       for (int k = lane; k < IVN; k += 64) imin[k] = r2max_bits;
     // tile that holds the particle; poses far outside any map (or NaN) visit no tile
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
       bool hit = valid && r2 <= P.r2max;       // :127
       const float aaf = bearing_f32((float)dy, (float)dx);
       const unsigned long long r2bits = (unsigned long long)__double_as_longlong(r2);
-      if constexpr (FAST) {
+      if constexpr (IVK) {
         if (use_iv) {
           // the interval that holds the bearing: one minimum serves every beam whose sector spans it.  Only a
           // bearing within rounding of a sector edge goes through the beam-by-beam test below.
@@ -518,6 +520,32 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
       nx = xs[p + stride]; ny = ys[p + stride]; nth = ths[p + stride];
       if (!STAGE && !GRID) npm = pm[p + stride];
     }
+    // smallest squared distance in the sector of the beam at sorted position k: the per-beam table, and with sector
+    // intervals also the intervals its sector spans (squared distances are not negative: their order as float64 is
+    // their order as bit patterns)
+    auto beam_r2bits = [&](int k) -> unsigned long long {
+      unsigned long long rb = rmin[G + k];
+      if constexpr (IVK) {
+        if (use_iv) {
+          const unsigned int span_k = s_ivbeam[k];
+          const unsigned long long* run = imin + (span_k & 0xffu);
+          const int cnt = (int)(span_k >> 8);
+          double best = __longlong_as_double((long long)rb);
+          // (the plain instruction: nothing here is a NaN, so the library minimum's quieting of operands is not needed)
+          auto lower = [](double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+          if (P.iv_cmin == P.iv_cmax) {                               // every sector spans as many intervals (evenly spaced beams)
+            for (int j = 0; j < P.iv_cmax; ++j) best = lower(best, __longlong_as_double((long long)run[j]));
+          } else {
+            for (int j = 0; j < P.iv_cmax; ++j) {
+              const double v = __longlong_as_double((long long)run[j]);
+              best = lower(best, j < cnt ? v : best);
+            }
+          }
+          rb = (unsigned long long)__double_as_longlong(best);
+        }
+      }
+      return rb;
+    };
     if (STAGE) {
       for (int k = lane; k < B; k += 64) {
         const double r2 = __longlong_as_double((long long)rmin[G + k]);
@@ -618,26 +646,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
         return (double)(ex - 1023) + (double)__builtin_amdgcn_logf((float)mant);
       };
       for (int k = lane; k < B; k += 64) {
-        unsigned long long rb = rmin[G + k];
-        if (use_iv) {
-          // the intervals the beam's sector spans (squared distances are not negative: their order as float64 is their
-          // order as bit patterns)
-          const unsigned int span_k = s_ivbeam[k];
-          const unsigned long long* run = imin + (span_k & 0xffu);
-          const int cnt = (int)(span_k >> 8);
-          double best = __longlong_as_double((long long)rb);
-          // (the plain instruction: nothing here is a NaN, so the library minimum's quieting of operands is not needed)
-          auto lower = [](double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
-          if (P.iv_cmin == P.iv_cmax) {                               // every sector spans as many intervals (evenly spaced beams)
-            for (int j = 0; j < P.iv_cmax; ++j) best = lower(best, __longlong_as_double((long long)run[j]));
-          } else {
-            for (int j = 0; j < P.iv_cmax; ++j) {
-              const double v = __longlong_as_double((long long)run[j]);
-              best = lower(best, j < cnt ? v : best);
-            }
-          }
-          rb = (unsigned long long)__double_as_longlong(best);
-        }
+        const unsigned long long rb = beam_r2bits(k);
         const double r2 = __longlong_as_double((long long)rb);
         const float num = (float)(r2 - s_zt[k]);                      // z^2 - z*^2, cancellation exact in float64
         const float2 zf = reinterpret_cast<const float2*>(s_el)[k];   // z*, eta * lambda * w_short
@@ -684,7 +693,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
         }
       };
       for (int k = lane; k < B; k += 64) {
-        const double r2 = __longlong_as_double((long long)rmin[G + k]);
+        const double r2 = __longlong_as_double((long long)beam_r2bits(k));
         double zd;
         if constexpr (sizeof(R) == 4) {
           // float32 square root refined by one Newton step in float64 (relative error ~1e-14);
@@ -840,7 +849,7 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
   const bool stage = ranges_out != nullptr;
   // log-weights only, float32 state, no range noise, measured ranges finite and >= 0: the float32 mixture
   const bool fast = !stage && !device_noise && dtype == MCLHIP_F32 && !product && !range_noise && c->zmeas_ok && MCL_FAST_LIKELIHOOD;
-  if (!fast || !MCL_FAST_INTERVALS) { P.iv_NE = 0; P.iv_cmax = 0; }
+  if (stage || !MCL_FAST_INTERVALS) { P.iv_NE = 0; P.iv_cmax = 0; }
   const size_t lds = ray_lds_bytes(P.B, P.G, P.NB, stage || product, kWavesPerBlock, 0, 0, P.iv_NE, P.iv_NB, P.iv_cmax);
   if (lds > 160 * 1024) return fail(c, MCLHIP_E_LIMIT, "beam table does not fit the kernel's LDS budget");
   int64_t blocks = (n + kWavesPerBlock - 1) / kWavesPerBlock;
