@@ -46,15 +46,16 @@ int launch_build_tiles(mclhip_ctx* c, const uint8_t* d_map) {
 
 // ---------------------------------------------------------------------------
 // Neighbourhood lists.  For every query tile of the grid (kQueryCells^2 cells; the grid extended by the ring
-// radius on each side) the obstacle cells of all 8x8 obstacle tiles that can hold a cell within reach of some
-// point of the query tile, concatenated nearest tile first: what a particle standing anywhere in that query
-// tile has to look at is then one contiguous slice.  The ring table names the obstacle tiles around the
-// 8x8 tile the query tile lies in; of those, the ones whose nearest cell is out of reach of the query tile
-// itself are left out.
+// radius on each side) the obstacle cells that can be within reach of some point of the query tile, nearest
+// obstacle tile first: what a particle standing anywhere in that query tile has to look at is then one
+// contiguous slice.  The ring table names the 8x8 obstacle tiles around the 8x8 tile the query tile lies in; of
+// those, the ones whose nearest cell is out of reach of the query tile are left out as a whole, and of the others
+// every cell is tested by itself (a list of whole tiles is half as long again: it covers a disc whose radius is
+// larger by a tile's diagonal).
 // ---------------------------------------------------------------------------
 struct NbrGeom {
   int TW, TH, n_ring, rtx, rty, ETW, ETH;   // obstacle tiles, ring, extended 8x8 tile grid
-  double res_x, res_y, reach2;
+  double res_x, res_y, reach2, cell_reach2;
 };
 
 // fewest whole cells between the query rows / columns [q0, q0 + kQueryCells) and the obstacle tile's [8 o, 8 o + 8)
@@ -68,49 +69,50 @@ __device__ inline bool in_reach(const NbrGeom& g, int qrow0, int qcol0, int y, i
   return gx * gx + gy * gy <= g.reach2;
 }
 
-__global__ void nbr_count_kernel(const uint32_t* __restrict__ tile_off, const uint16_t* __restrict__ ring, NbrGeom g,
-                                 uint32_t* __restrict__ cnt) {
+// One obstacle cell (row << 16 | col) against the query tile: a pose of the tile has its coordinate, in cells, in
+// [q0, q0 + kQueryCells), the cell stands at its own index; cell_reach2 holds a cell of slack for the rounding of
+// both.
+__device__ inline bool cell_in_reach(const NbrGeom& g, int qrow0, int qcol0, uint32_t e) {
+  const int col = (int)(e & 0xffffu), row = (int)(e >> 16);
+  const int dc = col < qcol0 ? qcol0 - col : (col > qcol0 + kQueryCells ? col - (qcol0 + kQueryCells) : 0);
+  const int dr = row < qrow0 ? qrow0 - row : (row > qrow0 + kQueryCells ? row - (qrow0 + kQueryCells) : 0);
+  const double gx = (double)dc * g.res_x, gy = (double)dr * g.res_y;
+  return gx * gx + gy * gy <= g.cell_reach2;
+}
+
+// One wavefront per query tile.  FILL == false: the length of its list into cnt; true: the list itself, from
+// nbr_off on.
+template <bool FILL>
+__global__ __launch_bounds__(256) void nbr_list_kernel(const uint32_t* __restrict__ tile_off,
+                                                       const uint32_t* __restrict__ cells, const uint16_t* __restrict__ ring,
+                                                       NbrGeom g, const uint32_t* __restrict__ nbr_off,
+                                                       uint32_t* __restrict__ out_buf) {
   const int SW = g.ETW << kQueryShift, SH = g.ETH << kQueryShift;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= SW * SH) return;
-  const int sy = t / SW, sx = t % SW;
+  const int lane = threadIdx.x & 63;
+  const int64_t t = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (t >= (int64_t)SW * SH) return;
+  const int sy = (int)(t / SW), sx = (int)(t % SW);
   const int ty = (sy >> kQueryShift) - g.rty, tx = (sx >> kQueryShift) - g.rtx;   // the 8x8 tile it lies in
   const int qrow0 = ty * 8 + (sy & ((1 << kQueryShift) - 1)) * kQueryCells;
   const int qcol0 = tx * 8 + (sx & ((1 << kQueryShift) - 1)) * kQueryCells;
-  uint32_t n = 0;
-  for (int r = 0; r < g.n_ring; ++r) {
-    const int y = ty + (int)(ring[r] >> 8) - 128, x = tx + (int)(ring[r] & 0xffu) - 128;
-    if (y < 0 || y >= g.TH || x < 0 || x >= g.TW) continue;
-    if (!in_reach(g, qrow0, qcol0, y, x)) continue;
-    const uint32_t* to = tile_off + ((size_t)y * g.TW + x);
-    n += to[1] - to[0];
-  }
-  cnt[t] = n;
-}
-
-// one wavefront per query tile
-__global__ __launch_bounds__(256) void nbr_fill_kernel(const uint32_t* __restrict__ tile_off,
-                                                       const uint32_t* __restrict__ cells, const uint16_t* __restrict__ ring,
-                                                       NbrGeom g, const uint32_t* __restrict__ nbr_off,
-                                                       uint32_t* __restrict__ nbr_cells) {
-  const int SW = g.ETW << kQueryShift, SH = g.ETH << kQueryShift;
-  const int lane = threadIdx.x & 63;
-  const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (t >= SW * SH) return;
-  const int sy = t / SW, sx = t % SW;
-  const int ty = (sy >> kQueryShift) - g.rty, tx = (sx >> kQueryShift) - g.rtx;
-  const int qrow0 = ty * 8 + (sy & ((1 << kQueryShift) - 1)) * kQueryCells;
-  const int qcol0 = tx * 8 + (sx & ((1 << kQueryShift) - 1)) * kQueryCells;
-  uint32_t out = nbr_off[t];
+  uint32_t out = FILL ? nbr_off[t] : 0u;
   for (int r = 0; r < g.n_ring; ++r) {
     const int y = ty + (int)(ring[r] >> 8) - 128, x = tx + (int)(ring[r] & 0xffu) - 128;
     if (y < 0 || y >= g.TH || x < 0 || x >= g.TW) continue;
     if (!in_reach(g, qrow0, qcol0, y, x)) continue;
     const uint32_t* to = tile_off + ((size_t)y * g.TW + x);
     const uint32_t o = to[0], n = to[1] - o;   // n <= 64
-    if ((uint32_t)lane < n) nbr_cells[out + lane] = cells[o + lane];
-    out += n;
+    if (n == 0) continue;
+    const uint32_t e = (uint32_t)lane < n ? cells[o + lane] : 0u;
+    const bool keep = (uint32_t)lane < n && cell_in_reach(g, qrow0, qcol0, e);
+    const unsigned long long km = __ballot(keep);
+    if (FILL && keep) {
+      const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+      out_buf[out + pos] = e;
+    }
+    out += (uint32_t)__popcll(km);
   }
+  if (!FILL && lane == 0) out_buf[t] = out;
 }
 
 static NbrGeom nbr_geom(const mclhip_ctx* c) {
@@ -119,21 +121,23 @@ static NbrGeom nbr_geom(const mclhip_ctx* c) {
   g.res_x = c->res_x; g.res_y = c->res_y;
   const double reach = c->z_max + 2.0 * (c->res_x + c->res_y);   // the ring table's own margin
   g.reach2 = reach * reach;
+  const double cell_reach = c->z_max + (c->res_x + c->res_y);
+  g.cell_reach2 = cell_reach * cell_reach;
   return g;
 }
 
 int launch_nbr_count(mclhip_ctx* c, uint32_t* d_cnt) {
   const int64_t ne = ((int64_t)c->ETW << kQueryShift) * ((int64_t)c->ETH << kQueryShift);
-  hipLaunchKernelGGL(nbr_count_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, c->stream, c->tile_off, c->ring,
-                     nbr_geom(c), d_cnt);
+  hipLaunchKernelGGL(nbr_list_kernel<false>, dim3((unsigned)((ne + 3) / 4)), dim3(256), 0, c->stream, c->tile_off, c->cells,
+                     c->ring, nbr_geom(c), (const uint32_t*)nullptr, d_cnt);
   MCL_HIP(c, hipGetLastError());
   return MCLHIP_OK;
 }
 
 int launch_nbr_fill(mclhip_ctx* c) {
   const int64_t ne = ((int64_t)c->ETW << kQueryShift) * ((int64_t)c->ETH << kQueryShift);
-  hipLaunchKernelGGL(nbr_fill_kernel, dim3((unsigned)((ne + 3) / 4)), dim3(256), 0, c->stream, c->tile_off, c->cells, c->ring,
-                     nbr_geom(c), c->nbr_off, c->nbr_cells);
+  hipLaunchKernelGGL(nbr_list_kernel<true>, dim3((unsigned)((ne + 3) / 4)), dim3(256), 0, c->stream, c->tile_off, c->cells,
+                     c->ring, nbr_geom(c), c->nbr_off, c->nbr_cells);
   MCL_HIP(c, hipGetLastError());
   return MCLHIP_OK;
 }

@@ -52,7 +52,7 @@ def huge():
 
 
 def test_map_structures_cost(huge):
-    """Neighbourhood lists of the 16384^2 map at 4 % occupancy: ~1.2e9 entries of four bytes plus offsets and bit
+    """Neighbourhood lists of the 16384^2 map at 4 % occupancy: ~0.9e9 entries of four bytes plus offsets and bit
     planes; built in well under a minute (host tile lists + device fill)."""
     print("set_map + set_sensor: %.1f s, %.2f GB of device memory, occupancy %.2f %%"
           % (huge["set_map_s"], huge["map_bytes"] / 1e9, 100 * huge["occ"]))
@@ -115,10 +115,12 @@ def test_whole_update_properties(huge):
 
 
 def test_map_beyond_the_list_limit_is_refused():
-    """At 16 % occupancy the neighbourhood lists of a 16384^2 map need more than 2^32 entries: a clear refusal, no
-    partial state."""
+    """With every fourth cell an obstacle the neighbourhood lists of a 16384^2 map need more than 2^32 entries (a
+    query tile of 8x8 cells sees about 5100 cells within reach, 4.2e6 tiles, a quarter of the cells occupied): a clear
+    refusal, no partial state."""
     from slam_amd import _lib, workload as W
-    grid = W.synthetic_map(N, target_occupancy=0.16)
+    grid = np.full((N, N), 255, np.uint8)
+    grid[::2, ::2] = 0
     sp = O.SensorParams()
     ctx = _lib.Context(0, _lib.F32)
     ctx.set_sensor(W.beam_angles(B), sp.z_max, sp.sigma_hit, sp.lambda_short, [sp.w_hit, sp.w_short, sp.w_max, sp.w_rand],
