@@ -80,7 +80,7 @@ RayParams make_ray_params(const mclhip_ctx* c) {
   P.tab_sorted = c->tab_sorted; P.perm = c->perm; P.lut = c->lut;
   P.ts_min = c->ts_min; P.ts_max = c->ts_max; P.inv_bw = c->inv_bw;
   P.relx = c->relx; P.G = c->G; P.ext_min = c->ext_min;
-  P.iv_NE = c->iv_NE; P.iv_NB = c->iv_NB; P.iv_cmax = c->iv_cmax; P.iv_cmin = c->iv_cmin; P.iv_edge = c->iv_edge; P.iv_beam = c->iv_beam; P.iv_lut = c->iv_lut;
+  P.iv_NE = c->iv_NE; P.iv_NB = c->iv_NB; P.iv_cmax = c->iv_cmax; P.iv_cmin = c->iv_cmin; P.iv_edge = c->iv_edge; P.iv_beam = c->iv_beam; P.iv_lut = c->iv_lut; P.iv_ends = c->iv_ends;
   P.iv_origin = c->iv_origin; P.iv_th_hi = c->iv_th_hi;
   P.half = c->half;
   P.two_pi_lo = M_PI * 2 - c->half;  // mc_localization.py:149
@@ -91,6 +91,7 @@ RayParams make_ray_params(const mclhip_ctx* c) {
   P.lambda = c->lambda;
   P.w_hit = c->w4[0]; P.w_short = c->w4[1]; P.w_max = c->w4[2]; P.w_rand = c->w4[3];
   P.p_rand = 1 / c->z_max;                               // range_sensor.py:64
+  P.redo_list = nullptr; P.redo_count = nullptr; P.list = nullptr; P.list_count = nullptr; P.sub_cap = 0;
   P.range_noise = nullptr;
   P.rn_sigma = 0.0; P.rn_seed = 0; P.rn_index0 = c->first_index;
   P.stamps = c->stamps;
@@ -190,6 +191,9 @@ static int ensure_capacity(mclhip_ctx* c, int64_t M) {
   MCL_TRY(dev_alloc(c, &c->irr, M * irr_record_bytes()));
   MCL_TRY(dev_alloc(c, &c->bases, M * run_base_bytes()));
   MCL_TRY(dev_alloc(c, &c->idx, M * sizeof(int64_t)));
+  MCL_TRY(dev_alloc(c, &c->redo_list, (M + mclhip_ctx::kRedoSlack) * sizeof(int32_t)));
+  MCL_TRY(dev_alloc(c, &c->redo_count, 64 * sizeof(uint32_t)));
+  c->redo_cap = M;
   if (c->noise) { (void)hipFree(c->noise); c->noise = nullptr; }
   c->cap = M;
   return MCLHIP_OK;
@@ -343,7 +347,7 @@ void mclhip_destroy(mclhip_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   fs_release(c);
-  void* ptrs[] = {c->obst, c->freeb, c->tile_off, c->cells, c->nbr_off, c->nbr_cells, c->tab_sorted, c->tab_orig, c->perm, c->inv_perm, c->lut, c->relx, c->iv_edge, c->iv_beam, c->iv_lut, c->zt, c->etalam, c->zmeas_stage, c->ring,
+  void* ptrs[] = {c->obst, c->freeb, c->tile_off, c->cells, c->nbr_off, c->nbr_cells, c->tab_sorted, c->tab_orig, c->perm, c->inv_perm, c->lut, c->relx, c->iv_edge, c->iv_beam, c->iv_lut, c->iv_ends, c->redo_list, c->redo_count, c->zt, c->etalam, c->zmeas_stage, c->ring,
                   c->px[0], c->px[1], c->py[0], c->py[1], c->pth[0], c->pth[1], c->w[0], c->w[1], c->logw, c->pm,
                   c->sx, c->sy, c->sth, c->sw, c->chunk_sums, c->scal, c->cdf_approx, c->cdf_exact, c->kscan,
                   c->fscan, c->blk_a, c->blk_b, c->irr, c->bases, c->idx, c->noise, c->counters, c->range_noise, c->inj_rows, c->stamps,
@@ -517,36 +521,50 @@ int mcl::set_sensor_table(mclhip_ctx* c, const double* tab_rad, int B, double z_
         }
         return best;
       };
-      bool ok = NE >= 2 && NE <= 255 && edge[0] <= 1e-9;
+      bool ok = NE >= 2 && NE <= 1023 && edge[0] <= 1e-9;
+      // every interval is much wider than the band around an edge in which float32 does not decide: a bearing is
+      // then near one edge at most, and a sector that holds an edge in its interior holds that whole band
+      for (int m = 0; m < NE && ok; ++m)
+        if ((m + 1 < NE ? edge[m + 1] : two_pi) - edge[m] < 1e-4) ok = false;
       std::vector<uint16_t> beam(B);
+      std::vector<uint32_t> ends(NE > 0 ? NE : 1, 0u);
       int cmax = 0, cmin = 1 << 30;
       for (int k = 0; k < B && ok; ++k) {
         const int m0 = index_of(reduced(ts[k] - half)), m1 = index_of(reduced(ts[k] + half));
         const int cnt = (m1 - m0 + NE) % NE;
-        if (cnt < 1 || cnt > 255) ok = false;
+        if (cnt < 1 || cnt > 63) { ok = false; break; }
         cmax = std::max(cmax, cnt); cmin = std::min(cmin, cnt);
-        beam[k] = (uint16_t)(m0 | (cnt << 8));
+        beam[k] = (uint16_t)(m0 | (cnt << 10));
+        // one sector may start and one may end at an edge (repeated beams, or different beams whose edges agree, leave
+        // the table to the beam-by-beam test)
+        if ((ends[m0] >> 21) & 1u) { ok = false; break; }
+        ends[m0] |= ((uint32_t)k << 11) | (1u << 21);
+        if ((ends[m1] >> 10) & 1u) { ok = false; break; }
+        ends[m1] |= (uint32_t)k | (1u << 10);
+        for (int j = 1; j < cnt; ++j) ends[(m0 + j) % NE] |= 1u << 22;
       }
       if (ok) {
         int NBI = 1;
-        while (NBI < 4 * NE) NBI <<= 1;
+        while (NBI < 2 * NE) NBI <<= 1;   // two-byte entries: the table costs what the four-per-interval one-byte table did
         std::vector<float> ef(NE + 1);
         for (int m = 0; m < NE; ++m) ef[m] = (float)edge[m];
         ef[0] = 0.0f;
         ef[NE] = (float)two_pi;
-        std::vector<uint8_t> ilut(NBI);
+        std::vector<uint16_t> ilut(NBI);
         for (int b = 0; b < NBI; ++b) {
           const float lower = (float)(two_pi * b / NBI);
           int m = 0;
           while (m + 1 < NE && ef[m + 1] <= lower) ++m;
-          ilut[b] = (uint8_t)m;
+          ilut[b] = (uint16_t)m;
         }
         MCL_TRY(dev_alloc(c, &c->iv_edge, ef.size() * sizeof(float)));
         MCL_TRY(dev_alloc(c, &c->iv_beam, B * sizeof(uint16_t)));
-        MCL_TRY(dev_alloc(c, &c->iv_lut, NBI));
+        MCL_TRY(dev_alloc(c, &c->iv_lut, NBI * sizeof(uint16_t)));
+        MCL_TRY(dev_alloc(c, &c->iv_ends, NE * sizeof(uint32_t)));
+        MCL_HIP(c, hipMemcpy(c->iv_ends, ends.data(), NE * sizeof(uint32_t), hipMemcpyHostToDevice));
         MCL_HIP(c, hipMemcpy(c->iv_edge, ef.data(), ef.size() * sizeof(float), hipMemcpyHostToDevice));
         MCL_HIP(c, hipMemcpy(c->iv_beam, beam.data(), B * sizeof(uint16_t), hipMemcpyHostToDevice));
-        MCL_HIP(c, hipMemcpy(c->iv_lut, ilut.data(), NBI, hipMemcpyHostToDevice));
+        MCL_HIP(c, hipMemcpy(c->iv_lut, ilut.data(), NBI * sizeof(uint16_t), hipMemcpyHostToDevice));
         c->iv_NE = NE; c->iv_NB = NBI; c->iv_cmax = cmax; c->iv_cmin = cmin; c->iv_origin = origin;
         c->iv_th_hi = two_pi - 2.0 * half - 1e-3;
       }

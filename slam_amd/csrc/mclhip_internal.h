@@ -55,14 +55,27 @@ struct RayParams {
   // intervals inside each of which the set of sectors that hold a bearing does not change -- a contiguous run of beams.
   // A cell that is not within rounding of an edge then costs ONE minimum (its interval's) instead of one per beam, and
   // a beam's range is the smallest of the few intervals its sector spans.  iv_NE == 0: not available for this table.
-  int iv_NE, iv_NB;            // intervals (<= 255), buckets of the look-up (a power of two)
+  int iv_NE, iv_NB;            // intervals (<= 1023), buckets of the look-up (a power of two)
   int iv_cmax, iv_cmin;        // most / fewest intervals a sector spans
   const float* iv_edge;        // [NE + 1] lower edge of every interval, measured from iv_origin; iv_edge[NE] = 2 pi
-  const uint16_t* iv_beam;     // [B] first interval | number of intervals << 8 of the beam at sorted position k
-  const uint8_t* iv_lut;       // [NB] bucket -> last interval that starts at or below the bucket's lower edge
+  const uint16_t* iv_beam;     // [B] first interval | number of intervals (<= 63) << 10 of the beam at sorted position k
+  const uint16_t* iv_lut;      // [NB] bucket -> last interval that starts at or below the bucket's lower edge
+  const uint32_t* iv_ends;     // [NE] per edge m (the lower edge of interval m): the one beam whose sector ENDS there (bits 0-9,
+                               // bit 10 = there is one), the one whose sector STARTS there (bits 11-20, bit 21), and bit 22 = some
+                               // sector holds the edge in its interior.  A bearing within rounding of the edge is decided for
+                               // exactly these beams with the reference's float64 predicate.
   double iv_origin;            // angle of edge 0 (the lowest sector edge)
-  double iv_th_hi;             // headings in [0, iv_th_hi] take this path: there the reference's predicate (one turn of
-                               // slack, mc_localization.py:148-149) is the circular one
+  double iv_th_hi;             // headings in [-iv_th_hi, iv_th_hi] take this path: there the reference's predicate (one turn
+                               // of slack either way, mc_localization.py:148-149) is the circular one -- beam angle + heading
+                               // stays within (-2 pi + half-angle, 4 pi - half-angle), and a bearing in [0, 2 pi) is then
+                               // never two turns away from it
+  // Two launches of the float32-mixture path: the interval-only kernel files the particles it does not serve ...
+  int32_t* redo_list;          // 64 lists of sub_cap places each (blocks b, b + 64, ... append to list b % 64)
+  uint32_t* redo_count;        // [64], zero before the launch
+  int64_t sub_cap;
+  // ... and the launch that follows takes its particles from that list
+  const int32_t* list;
+  const uint32_t* list_count;
   // beam mixture
   const double* zt;      // measured range per beam, in sorted-angle order
   const double* etalam;  // eta_short * lambda_short per beam, in sorted-angle order
@@ -134,7 +147,7 @@ struct mclhip_ctx {
   uint16_t* perm = nullptr;
   uint16_t* inv_perm = nullptr;
   uint16_t* lut = nullptr;
-  float* iv_edge = nullptr; uint16_t* iv_beam = nullptr; uint8_t* iv_lut = nullptr;   // sector intervals (see RayParams)
+  float* iv_edge = nullptr; uint16_t* iv_beam = nullptr; uint16_t* iv_lut = nullptr; uint32_t* iv_ends = nullptr;   // sector intervals (see RayParams)
   int iv_NE = 0, iv_NB = 0, iv_cmax = 0, iv_cmin = 0; double iv_origin = 0.0, iv_th_hi = 0.0;
   float* relx = nullptr;
   int G = 0;
@@ -156,6 +169,8 @@ struct mclhip_ctx {
 
   // particles (structure of arrays; pose arrays are float or double by dtype)
   int64_t M = 0, cap = 0;
+  int32_t* redo_list = nullptr; uint32_t* redo_count = nullptr; int64_t redo_cap = 0;   // particles the interval-only sector query left over
+  static constexpr int64_t kRedoSlack = 64 * 16 * 2;   // the 64 lists are rounded up to whole blocks of waves
   void* px[2] = {nullptr, nullptr};
   void* py[2] = {nullptr, nullptr};
   void* pth[2] = {nullptr, nullptr};

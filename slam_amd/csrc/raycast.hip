@@ -28,6 +28,7 @@
 // particle.
 //
 // Compiled with -ffp-contract=off.
+#include <algorithm>
 #include <cstdlib>
 
 #include "device_rng.h"
@@ -44,7 +45,12 @@ constexpr int kWavesPerBlock = MCL_WPB;
 #define MCL_GROUP 4
 #endif
 constexpr int kGroup = MCL_GROUP;   // beams examined per step of the matching loop
-constexpr int kWaveScratch = 128;     // u32 words of per-wave LDS scratch: the ring of cells waiting to be matched
+constexpr int kCapSpan = 16;
+constexpr int cap_buckets(int cap) { int n = 1; while (n < 2 * cap) n <<= 1; return n; }
+constexpr int kEdgeQueue = 32;        // cells on a sector edge that a particle can park (interval path); more: the particle is done entry by entry
+constexpr int kSubLists = 64;         // the list of left-over particles is kept as this many lists with a counter each (blocks b, b + 64, ... share one)
+constexpr int kFiled = 16;            // particles an interval-only wave notes before it appends them to the list in one go
+constexpr int kWaveScratch = 128 + 2 * kEdgeQueue + 2 + kFiled + 2;   // u32 words of per-wave LDS scratch: the ring of cells waiting to be matched, the parked cells (u64 each), their count, the noted particles, their count
 
 // ---- cross-lane helpers on the DPP path (no LDS round trip) ----------------
 #define MCL_DPP_I32(old, v, ctrl, rmask) __builtin_amdgcn_update_dpp((old), (v), (ctrl), (rmask), 0xf, false)
@@ -164,6 +170,10 @@ __device__ __attribute__((noinline)) double slow_log(double v) { return log(v); 
 #ifndef MCL_FAST_WAVES
 #define MCL_FAST_WAVES 7
 #endif
+// The interval-only instantiation.  Measured at 2^20 x 180: 7 waves 0.898 ms, 8 waves 0.883 ms, 9 waves 0.990 ms.
+#ifndef MCL_IVONLY_WAVES
+#define MCL_IVONLY_WAVES 8
+#endif
 // Blocks of the particle-filter launch (each wave then loops over particles).  Seven blocks of four waves fit a
 // compute unit, 1792 the chip; the launch wants several rounds of that, so that blocks which draw expensive particles
 // do not leave the chip idle at the end, but not so many that the beam tables are staged too often.  Measured at
@@ -180,48 +190,71 @@ __device__ __attribute__((noinline)) double slow_log(double v) { return log(v); 
 // between predicted and measured range, which the Gaussian term amplifies by d / sigma^2 -- formed from the exact
 // float64 squared distance as (r2 - z*^2) / (z + z*), so that it carries float32 RELATIVE accuracy however close
 // the two ranges are.
+// IVONLY (with FAST): the kernel serves only the particles that take the sector-interval path and files the others --
+// headings outside the interval path's range, and the rare particle with a cell on a sector edge that intervals cannot
+// express -- in P.redo_list; nothing of the entry-by-entry test is compiled in (51 instead of 72 vector registers,
+// hardly any scalar-register spill).  LISTED: the particles are those of P.list (what an IVONLY launch left over).
+// CAP (with IVONLY): the LDS arrays are laid out for CAP beams, CAP intervals, sectors of at most kCapSpan intervals
+// and a look-up of cap_buckets(CAP) entries, whatever the table at hand needs: every address is then a compile-time
+// offset from the block's or the wave's base instead of a value kept in a scalar register.
 template <typename T, bool STAGE, bool PRODUCT, bool GRID = false, int WPB = kWavesPerBlock, bool RNOISE = false,
-          bool FAST = false>
-__global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST ? MCL_FAST_WAVES : (sizeof(T) == 4 ? MCL_RAY_WAVES : 4)))) void raycast_kernel(
+          bool FAST = false, bool IVONLY = false, bool LISTED = false, int CAP = 0>
+// (waves per SIMD as a closed range: with only a lower bound the compiler budgets scalar registers for the ten waves
+// a small vector-register count would allow -- 80 instead of 96 -- and spills the rest into vector lanes)
+#define MCL_RAY_OCC(T, GRID, WPB, FAST, IVONLY) (GRID ? WPB / 4 : (IVONLY ? MCL_IVONLY_WAVES : (FAST ? MCL_FAST_WAVES : (sizeof(T) == 4 ? MCL_RAY_WAVES : 4))))
+__global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
+                          amdgpu_waves_per_eu(MCL_RAY_OCC(T, GRID, WPB, FAST, IVONLY), MCL_RAY_OCC(T, GRID, WPB, FAST, IVONLY)))) void raycast_kernel(
     RayParams P, const T* __restrict__ xs, const T* __restrict__ ys, const T* __restrict__ ths,
     const uint8_t* __restrict__ pm, int64_t n, double* __restrict__ w_out, double* __restrict__ logw_out,
     double* __restrict__ ranges_out, int32_t* __restrict__ hits_out) {
   extern __shared__ __align__(16) unsigned char smem[];
+  // LISTED: the launch is sized for every particle, the list is usually short: a block beyond it leaves at once
+  if constexpr (LISTED) {
+    if ((int64_t)(blockIdx.x / kSubLists) * WPB >= (int64_t)P.list_count[blockIdx.x % kSubLists]) return;
+  }
   const int B = P.B, NB = P.NB;
   // GRID: the beam table holds the classes of (heading, beam) entries that share a bearing; NE entries
   const int NE = GRID ? P.g_NE : 0;
   const int NT = GRID ? P.g_B0 : B;                               // rows of the per-beam mixture tables
-  // block-wide tables
+  // block-wide tables.  L*: the dimensions the arrays are laid out for -- the table's own, or the instantiation's capacity
+  constexpr bool STATIC_L = IVONLY && CAP > 0;
+  const int LB = STATIC_L ? CAP : B;
+  const int LNT = GRID ? P.g_B0 : LB;
   double* s_ts = reinterpret_cast<double*>(smem);                 // [B] sorted beam angles
-  double* s_zt = s_ts + B;                                        // [NT] measured range (sorted order; GRID: per beam of one heading)
-  double* s_el = s_zt + NT;                                       // [NT] eta*lambda (GRID: exp(-lambda * z_meas))
-  unsigned long long* s_rmin_all = reinterpret_cast<unsigned long long*>(s_el + NT);
-  const int NXP = P.G + B + kGroup;                              // extended table + one group of padding
+  double* s_zt = s_ts + LB;                                       // [NT] measured range (sorted order; GRID: per beam of one heading)
+  double* s_el = s_zt + LNT;                                      // [NT] eta*lambda (GRID: exp(-lambda * z_meas))
+  unsigned long long* s_rmin_all = reinterpret_cast<unsigned long long*>(s_el + LNT);
+  const int NXP = IVONLY ? 0 : P.G + B + kGroup;                 // extended table + one group of padding
   const int RS = NXP + NE + (GRID ? B : 0);                      // per wave: minima per table entry, then (GRID) per entry, and a double per class
-  unsigned long long* s_aux_all = s_rmin_all + (size_t)WPB * RS;
-  // per wave, the smallest squared distance per sector interval (see RayParams::iv_*); not for the staged query
-  // (which also wants the hit cell) nor for the histogram filter's classes
+  // With sector intervals (see RayParams::iv_*; not for the staged query, which also wants the hit cell, nor for the
+  // histogram filter's classes) the wave's table holds the smallest squared distance per INTERVAL -- iv_NE entries and
+  // the first iv_cmax again behind them, so that a sector that wraps reads on -- for a particle that takes the interval
+  // path, and per table entry for one that does not: one array, sized for the larger of the two.
   constexpr bool IVK = !STAGE && !GRID;
   const int IVN = IVK ? P.iv_NE : 0;
-  unsigned long long* s_imin_all = s_aux_all + (size_t)((STAGE || PRODUCT) ? WPB * RS : 0);
-  const int IVS = IVK ? P.iv_NE + P.iv_cmax : 0;   // per wave: the minima, then the first iv_cmax again (a sector that wraps reads on)
-  unsigned int* s_walk_all = reinterpret_cast<unsigned int*>(s_imin_all + (size_t)WPB * IVS);
+  const int IVS = IVK ? P.iv_NE + P.iv_cmax : 0;
+  const int LIVN = STATIC_L ? CAP : IVN;
+  const int LNBI = STATIC_L ? cap_buckets(CAP) : P.iv_NB;
+  const int TS = STATIC_L ? CAP + kCapSpan : (RS > IVS ? RS : IVS);   // entries of the per-wave table
+  unsigned long long* s_aux_all = s_rmin_all + (size_t)WPB * TS;
+  unsigned int* s_walk_all = reinterpret_cast<unsigned int*>(s_aux_all + (size_t)((STAGE || PRODUCT) ? WPB * RS : 0));
   float* s_relx = reinterpret_cast<float*>(s_walk_all + (size_t)WPB * kWaveScratch);  // [G + B] extended angle table
   unsigned short* s_perm = reinterpret_cast<unsigned short*>(s_relx + NXP);
-  unsigned short* s_lut = s_perm + B;
-  unsigned int* s_cls = reinterpret_cast<unsigned int*>(s_lut + ((NB + B + 1) & ~1) - B);   // [NE] class << 20 | heading << 10 | beam of entry e (GRID), 4-byte aligned
+  unsigned short* s_lut = s_perm + (IVONLY ? 0 : B);
+  unsigned int* s_cls = reinterpret_cast<unsigned int*>(s_lut + (IVONLY ? 0 : ((NB + B + 1) & ~1) - B));   // [NE] class << 20 | heading << 10 | beam of entry e (GRID), 4-byte aligned
   // GRID: what the entry-by-entry test at a sector edge reads -- the entries of every class and the two terms of an entry's own angle
   double* s_ang = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(s_cls + NE) + 7) & ~(uintptr_t)7);   // [B0] beam angles, [D] heading angles (radians)
   unsigned short* s_member = reinterpret_cast<unsigned short*>(s_ang + (GRID ? P.g_B0 + P.g_D : 0));   // [NE] entries by class
   unsigned short* s_first = s_member + NE;                                                     // [B + 1] start of every class in s_member
   // the interval tables (never together with GRID) stand where the class tables would
   float* s_ivedge = reinterpret_cast<float*>(s_cls);                                           // [IVN + 1]
-  unsigned short* s_ivbeam = reinterpret_cast<unsigned short*>(s_ivedge + IVN + 1);            // [B]
-  unsigned char* s_ivlut = reinterpret_cast<unsigned char*>(s_ivbeam + B);                     // [iv_NB]
+  unsigned short* s_ivbeam = reinterpret_cast<unsigned short*>(s_ivedge + LIVN + 1);           // [B]
+  unsigned short* s_ivlut = s_ivbeam + LB;                                                      // [iv_NB]
+  unsigned int* s_ivends = reinterpret_cast<unsigned int*>(s_ivlut + ((LNBI + LB + 1) & ~1) - LB);   // [IVN], 4-byte aligned
 
   for (int k = threadIdx.x; k < B; k += blockDim.x) {
     s_ts[k] = P.tab_sorted[k];
-    s_perm[k] = P.perm[k];
+    if (!IVONLY) s_perm[k] = P.perm[k];
   }
   if (!STAGE)
     for (int k = threadIdx.x; k < NT; k += blockDim.x) {
@@ -239,22 +272,57 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
     for (int k = threadIdx.x; k <= B; k += blockDim.x) s_first[k] = P.g_cls_first[k];
     for (int k = threadIdx.x; k < P.g_B0 + P.g_D; k += blockDim.x) s_ang[k] = P.g_ar[k];   // one array: beams, then headings
   }
-  for (int k = threadIdx.x; k < NXP; k += blockDim.x) s_relx[k] = (k < P.G + B) ? P.relx[k] : 1.0e30f;  // padding: beyond any window
-  for (int k = threadIdx.x; k < NB; k += blockDim.x) s_lut[k] = P.lut[k];
+  if (!IVONLY) {
+    for (int k = threadIdx.x; k < NXP; k += blockDim.x) s_relx[k] = (k < P.G + B) ? P.relx[k] : 1.0e30f;  // padding: beyond any window
+    for (int k = threadIdx.x; k < NB; k += blockDim.x) s_lut[k] = P.lut[k];
+  }
   if (IVK && IVN > 0) {
     for (int k = threadIdx.x; k <= IVN; k += blockDim.x) s_ivedge[k] = P.iv_edge[k];
     for (int k = threadIdx.x; k < B; k += blockDim.x) s_ivbeam[k] = P.iv_beam[k];
     for (int k = threadIdx.x; k < P.iv_NB; k += blockDim.x) s_ivlut[k] = P.iv_lut[k];
+    for (int k = threadIdx.x; k < IVN; k += blockDim.x) s_ivends[k] = P.iv_ends[k];
   }
   __syncthreads();
 
-  const int lane = threadIdx.x & 63;
+  // The map fields arrive as one eight-register load; copied out one by one (opaque to the compiler) they are separate
+  // values to the register allocator, which otherwise spills and refills the eight as a block for every use of one.
+  const uint32_t* nbr_off = P.nbr_off;
+  const uint32_t* nbr_cells = P.nbr_cells;
+  int ETW = P.ETW, ETH = P.ETH, rtx = P.rtx, rty = P.rty;
+  asm volatile("" : "+s"(nbr_off), "+s"(nbr_cells), "+s"(ETW), "+s"(ETH), "+s"(rtx), "+s"(rty));
+  // likewise these arguments.  (Not the pose pointers: one that has gone through this is no longer known to point to
+  // read-only memory, its loads become vector loads and the pose lives in vector registers -- measured slower.)
+  asm volatile("" : "+s"(logw_out), "+s"(n));
+  int32_t* redo_list = P.redo_list + (size_t)(blockIdx.x % kSubLists) * P.sub_cap;
+  uint32_t* redo_count = P.redo_count + (blockIdx.x % kSubLists);
+  asm volatile("" : "+s"(redo_list), "+s"(redo_count));
+  const int lane0 = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: particle index, pose and slice bounds live in scalar registers
-  unsigned long long* const rmin = s_rmin_all + (size_t)wv * RS;   // per extended-table entry: bits of the smallest r2
+  unsigned long long* const rmin = s_rmin_all + (size_t)wv * TS;   // per extended-table entry (or per interval): bits of the smallest r2
   unsigned long long* const emin = rmin + NXP;                     // GRID: per entry, what only its own angle let in
   unsigned long long* const aux = s_aux_all + (size_t)wv * RS;     // STAGE: hit cell per entry; PRODUCT: p_k in caller order
   unsigned int* const ring = s_walk_all + (size_t)wv * kWaveScratch;   // [128] cells waiting to be matched
-  unsigned long long* const imin = s_imin_all + (size_t)wv * IVS;      // minima per sector interval
+  unsigned long long* const edgeq = reinterpret_cast<unsigned long long*>(ring + 128);   // [kEdgeQueue] edge << 32 | cell
+  unsigned int* const edge_cnt = ring + 128 + 2 * kEdgeQueue;
+  // IVONLY: the particles this wave leaves to the launch that follows are noted here and appended to the list kFiled
+  // at a time -- one atomic per wave and batch, not per particle: a cloud whose headings are all outside the interval
+  // path's range would otherwise queue a million atomics on one counter.
+  unsigned int* const filed = ring + 128 + 2 * kEdgeQueue + 2;
+  unsigned int* const filed_cnt = filed + kFiled;
+  auto flush_filed = [&](int lane_) {
+    const int nf = __builtin_amdgcn_readfirstlane((int)filed_cnt[0]);
+    if (nf > 0) {
+      unsigned int base = 0u;
+      if (lane_ == 0) base = atomicAdd(redo_count, (unsigned int)nf);
+      base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+      if (lane_ < nf) redo_list[base + lane_] = (int32_t)filed[lane_];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (lane_ == 0) filed_cnt[0] = 0u;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+  };
+  if (IVONLY && lane0 == 0) filed_cnt[0] = 0u;
+  unsigned long long* const imin = rmin;                               // the same array read as minima per sector interval
   const float iv_originf = (float)P.iv_origin, iv_inv_bwf = (float)((double)P.iv_NB / kTwoPi), iv_th_hif = (float)P.iv_th_hi;
   const float iv_nearf = (float)kEdgeEps + 3e-6f;     // closer than this to a sector edge, float32 does not decide
 
@@ -282,22 +350,38 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
   unsigned long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   const int64_t stride = (int64_t)gridDim.x * WPB;
-  int64_t p = (int64_t)blockIdx.x * WPB + wv;
+  // The wave's next particle: every stride-th one, or (LISTED) the one every stride-th place of the list names.
+  // (LISTED: block b serves list b % kSubLists together with blocks b + kSubLists, b + 2 kSubLists, ...)
+  const int32_t* const my_list = LISTED ? P.list + (size_t)(blockIdx.x % kSubLists) * P.sub_cap : nullptr;
+  if constexpr (LISTED) n = (int64_t)P.list_count[blockIdx.x % kSubLists];
+  const int64_t step = LISTED ? (int64_t)(gridDim.x / kSubLists) * WPB : stride;
+  int64_t place = (LISTED ? (int64_t)(blockIdx.x / kSubLists) : (int64_t)blockIdx.x) * WPB + wv - step;
+  int64_t p = 0, p_next = 0;
+  auto next_particle = [&]() -> bool {
+    place += step;
+    if (place >= n) return false;
+    p_next = LISTED ? (int64_t)my_list[place] : place;
+    return true;
+  };
   T nx = (T)0, ny = (T)0, nth = (T)0;
   unsigned char npm = 0;
-  if (p < n) { nx = xs[p]; ny = ys[p]; nth = ths[p]; if (!STAGE && !GRID) npm = pm[p]; }
-  for (; p < n; p += stride) {
+  bool have = next_particle();
+  if (have) { nx = xs[p_next]; ny = ys[p_next]; nth = ths[p_next]; if (!STAGE && !GRID) npm = pm[p_next]; }
+  bool entry_by_entry = false;   // the particle at hand is being done again without sector intervals
+  while (have) {
     STAMP(7);
+    p = p_next;
+    // the lane index is made opaque once per particle: comparisons against it are then formed where they are used
+    // (one instruction) instead of being kept as 64-bit masks in scalar registers that spill
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
     const double x = (double)nx, y = (double)ny, th = (double)nth;
     const bool on_free = npm != 0;
-    for (int k = lane; k < RS; k += 64) {
-      rmin[k] = r2max_bits;
-      if (STAGE) aux[k] = 0xffffffffull;
-    }
-    // headings for which the reference's predicate is the circular one take the interval path (wave-uniform)
-    const bool use_iv = IVK && IVN > 0 && (float)th >= 0.0f && (float)th <= iv_th_hif;
-    if (use_iv)
-      for (int k = lane; k < IVN; k += 64) imin[k] = r2max_bits;
+    // headings for which the reference's predicate is the circular one take the interval path (wave-uniform); a
+    // particle is done again entry by entry when a cell on a sector edge cannot be filed under intervals (see below)
+    const bool use_iv = IVK && IVN > 0 && !entry_by_entry && (float)th >= -iv_th_hif && (float)th <= iv_th_hif;
+    entry_by_entry = false;
+    bool lane_redo = false;
     // tile that holds the particle; poses far outside any map (or NaN) visit no tile
     // (a product instead of a division: an index off by one at an exact tile edge is covered by the
     // ring table's two cells of slack)
@@ -308,9 +392,9 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
     // the particle's slice of neighbourhood cells; NaN / infinite headings match no beam
     unsigned int first_cell = 0u, n_cells = 0u;
     {
-      const int ex = tcx + P.rtx, ey = tcy + P.rty;
-      if (pose_ok && fabs(th) < INFINITY && ex >= 0 && ex < P.ETW && ey >= 0 && ey < P.ETH) {
-        const unsigned int* no = P.nbr_off + ((size_t)ey * P.ETW + ex);
+      const int ex = tcx + rtx, ey = tcy + rty;
+      if (pose_ok && fabs(th) < INFINITY && ex >= 0 && ex < ETW && ey >= 0 && ey < ETH && (!IVONLY || use_iv)) {
+        const unsigned int* no = nbr_off + ((size_t)ey * ETW + ex);
         first_cell = no[0];
         n_cells = no[1] - first_cell;
       }
@@ -333,9 +417,8 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
         if (use_iv) {
           // the interval that holds the bearing: one minimum serves every beam whose sector spans it.  Only a
           // bearing within rounding of a sector edge goes through the beam-by-beam test below.
-          float a = (aaf - thf) - iv_originf;
-          a += a < 0.0f ? 6.2831853071795865f : 0.0f;
-          a -= a >= 6.2831853071795865f ? 6.2831853071795865f : 0.0f;
+          float a = (aaf - thf) - iv_originf;                         // in (-4 pi, 5 pi) for the headings of this path
+          a = fmaf(-6.2831853071795865f, floorf(a * 0.15915494309189535f), a);   // [0, 2 pi) up to rounding; the ends are edges
           int bkt = (int)(a * iv_inv_bwf);
           bkt = bkt < 0 ? 0 : (bkt > P.iv_NB - 1 ? P.iv_NB - 1 : bkt);
           int m = s_ivlut[bkt];                 // a bucket is a quarter of the average interval: at most one step as a rule
@@ -344,12 +427,21 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
             ++m; e0 = e1; e1 = s_ivedge[m + 1];
             while (e1 <= a && m + 1 < IVN) { ++m; e0 = e1; e1 = s_ivedge[m + 1]; }
           }
-          const bool near_edge = !((a - e0 >= iv_nearf) && (e1 - a >= iv_nearf));   // also NaN
+          const bool at_lower = !(a - e0 >= iv_nearf);                              // also NaN
+          const bool near_edge = at_lower || !(e1 - a >= iv_nearf);
           if (hit && !near_edge) atomicMin(&imin[m], r2bits);
-          hit = hit && near_edge;
+          if (hit && near_edge) {
+            // within rounding of edge E: parked, decided in float64 after the walk (rare; keeps the call out of this loop)
+            COUNTL(2);
+            const unsigned int E = (unsigned int)(at_lower ? m : (m + 1 == IVN ? 0 : m + 1));
+            const unsigned int pos = atomicAdd(edge_cnt, 1u);
+            if (pos < (unsigned int)kEdgeQueue) edgeq[pos] = ((unsigned long long)E << 32) | e;
+            else lane_redo = true;
+          }
+          hit = false;
         }
       }
-      if (hit) {
+      if (!IVONLY && hit) {
         COUNTL(2);
         const unsigned long long cellbits = (unsigned long long)((unsigned int)row * (unsigned int)P.W + (unsigned int)col);
         // beams whose table angle lies within `reach` of aa - th + c*2pi, c in {-1, 0, 1}
@@ -455,6 +547,14 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
     };
 
     STAMP(0);
+    {
+      const int n_clear = use_iv ? IVN : RS;
+      for (int k = lane; k < n_clear; k += 64) {
+        rmin[k] = r2max_bits;
+        if (STAGE) aux[k] = 0xffffffffull;
+      }
+      if (IVK && lane == 0) edge_cnt[0] = 0u;
+    }
     for (int phase = 0; phase < (STAGE ? 2 : 1); ++phase) {
       int q_head = 0, q_count = 0;   // wave-uniform state of the ring of cells waiting to be matched
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -462,12 +562,12 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
       // float64 test follows in match_cell) puts within z_max are queued in a 128-entry LDS
       // ring; whenever 64 are waiting they are matched together, so that the expensive part
       // runs with (almost) every lane busy although the slice holds many cells out of range.
-      unsigned int e_next = (lane < (int)n_cells) ? P.nbr_cells[first_cell + lane] : 0u;
+      unsigned int e_next = (lane < (int)n_cells) ? nbr_cells[first_cell + lane] : 0u;
       STAMP(2);
       for (unsigned int sb = 0; sb < n_cells; sb += 64) {
         const unsigned int e = e_next;
         COUNT(0);
-        if (sb + 64 + lane < n_cells) e_next = P.nbr_cells[first_cell + sb + 64 + lane];   // next batch in flight
+        if (sb + 64 + lane < n_cells) e_next = nbr_cells[first_cell + sb + 64 + lane];   // next batch in flight
         const float cdx = (float)(e & 0xffffu) * P.res_xf - xf;
         const float cdy = (float)(e >> 16) * P.res_yf - yf;
         const bool keep = (sb + lane < n_cells) && (cdx * cdx + cdy * cdy <= disk_r2);
@@ -495,7 +595,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       // a beam that also has a seam image keeps the smaller of the two minima in both entries
       // (entry G + k is beam k; entry g < G is the image of beam B - G + g)
-      if (lane < G) {
+      if (!use_iv && lane < G) {
         const int real = B + lane;   // == G + (B - G + lane)
         if (!STAGE || phase == 0) {
           const unsigned long long a = rmin[lane], b = rmin[real];
@@ -509,6 +609,44 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
+    if constexpr (IVK) {
+      if (use_iv) {
+        // The parked cells.  Sectors that hold edge E in their interior hold the cell; the one sector that ends at E
+        // and the one that starts there are asked with the reference's predicate in float64
+        // (mc_localization.py:148-149).  The interval below E serves the interior sectors and the ending one, the
+        // interval above it the interior ones and the starting one: every outcome but one is a choice of these two
+        // minima, and that one -- both refuse while interior sectors exist -- sends the particle through the
+        // entry-by-entry test.
+        const int nq = __builtin_amdgcn_readfirstlane((int)edge_cnt[0]);
+        if (nq > 0) {
+          if (lane < nq && lane < kEdgeQueue) {
+            const unsigned long long q = edgeq[lane];
+            const unsigned int e = (unsigned int)q;
+            const int E = (int)(q >> 32);
+            const int col = (int)(e & 0xffffu), row = (int)(e >> 16);
+            const double dx = (double)((float)col * P.res_xf) - x, dy = (double)((float)row * P.res_yf) - y;   // as in match_cell
+            const unsigned long long r2bits = (unsigned long long)__double_as_longlong(dx * dx + dy * dy);
+            const int left = E == 0 ? IVN - 1 : E - 1, right = E;
+            const unsigned int ends = s_ivends[E];
+            const double a_exact = exact_bearing(dy, dx);            // :133-135
+            auto refuses = [&](unsigned int k) {
+              const double de = fabs((s_ts[k] + th) - a_exact);      // :143, :148
+              return !((de <= P.half) || (de >= P.two_pi_lo && de <= P.two_pi_hi));   // :149
+            };
+            const bool no_end = ((ends >> 10) & 1u) && refuses(ends & 0x3ffu);
+            const bool no_start = ((ends >> 21) & 1u) && refuses((ends >> 11) & 0x3ffu);
+            if (!no_end) atomicMin(&imin[left], r2bits);
+            else if (no_start && ((ends >> 22) & 1u)) lane_redo = true;
+            if (!no_start) atomicMin(&imin[right], r2bits);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+      }
+      if (!IVONLY && use_iv && __ballot(lane_redo) != 0ull) {   // (rare) the same particle again, entry by entry; its pose is still at hand
+        entry_by_entry = true;
+        continue;
+      }
+    }
 
     // ranges -> beam mixture -> weight
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -516,21 +654,34 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
       for (int k = lane; k < P.iv_cmax; k += 64) imin[IVN + k] = imin[k];
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
-    if (p + stride < n) {   // next pose in flight while this particle's weight is computed
-      nx = xs[p + stride]; ny = ys[p + stride]; nth = ths[p + stride];
-      if (!STAGE && !GRID) npm = pm[p + stride];
+    have = next_particle();
+    if (have) {   // next pose in flight while this particle's weight is computed
+      nx = xs[p_next]; ny = ys[p_next]; nth = ths[p_next];
+      if (!STAGE && !GRID) npm = pm[p_next];
+    }
+    if constexpr (IVONLY) {
+      // not for this kernel: the heading is outside the interval path's range, or a cell on a sector edge asked for
+      // the entry-by-entry test; the particle is filed for the launch that follows
+      if (!use_iv || __ballot(lane_redo) != 0ull) {
+        const int nf = __builtin_amdgcn_readfirstlane((int)filed_cnt[0]);
+        if (lane == 0) { filed[nf] = (unsigned int)p; filed_cnt[0] = (unsigned int)(nf + 1); }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (nf + 1 == kFiled) flush_filed(lane);
+        continue;
+      }
     }
     // smallest squared distance in the sector of the beam at sorted position k: the per-beam table, and with sector
     // intervals also the intervals its sector spans (squared distances are not negative: their order as float64 is
     // their order as bit patterns)
     auto beam_r2bits = [&](int k) -> unsigned long long {
-      unsigned long long rb = rmin[G + k];
+      unsigned long long rb = r2max_bits;
+      if (!use_iv) rb = rmin[G + k];
       if constexpr (IVK) {
         if (use_iv) {
           const unsigned int span_k = s_ivbeam[k];
-          const unsigned long long* run = imin + (span_k & 0xffu);
-          const int cnt = (int)(span_k >> 8);
-          double best = __longlong_as_double((long long)rb);
+          const unsigned long long* run = imin + (span_k & 0x3ffu);
+          const int cnt = (int)(span_k >> 10);
+          double best = P.r2max;
           // (the plain instruction: nothing here is a NaN, so the library minimum's quieting of operands is not needed)
           auto lower = [](double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
           if (P.iv_cmin == P.iv_cmax) {                               // every sector spans as many intervals (evenly spaced beams)
@@ -769,6 +920,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     STAMP(6);
   }
+  if constexpr (IVONLY) flush_filed(lane0);
 #ifdef MCL_STAMPS
   if (lane == 0)
     for (int i = 0; i < 8; ++i) atomicAdd(&P.stamps[i], acc[i]);
@@ -780,18 +932,21 @@ __global__ __launch_bounds__(64 * WPB, (WPB != kWavesPerBlock ? WPB / 4 : (FAST 
 }
 
 static size_t ray_lds_bytes(int B, int G, int NB, bool aux, int waves = kWavesPerBlock, int NE = 0, int B0 = 0, int iv_NE = 0,
-                            int iv_NB = 0, int iv_cmax = 0) {
-  const int NXP = B + G + kGroup;
+                            int iv_NB = 0, int iv_cmax = 0, bool ivonly = false, int cap = 0) {
+  if (ivonly && cap > 0) {   // the interval-only kernel's fixed layout
+    B = cap; iv_NE = cap; iv_cmax = kCapSpan; iv_NB = cap_buckets(cap);
+  }
+  const int NXP = ivonly ? 0 : B + G + kGroup;
   const int NT = NE ? B0 : B;
+  const int RS = NXP + NE + (NE ? B : 0);
+  const int TS = std::max(RS, iv_NE ? iv_NE + iv_cmax : 0);                    // per-wave table: per entry or per interval
   size_t s = (size_t)(B + 2 * NT) * sizeof(double);
-  s += (size_t)waves * (NXP + NE + (NE ? B : 0)) * sizeof(unsigned long long) * (aux ? 2 : 1);
+  s += (size_t)waves * (TS + (aux ? RS : 0)) * sizeof(unsigned long long);
   s += (size_t)waves * kWaveScratch * sizeof(unsigned int);
   s += (size_t)NXP * sizeof(float);
-  s += ((size_t)B + NB + 4) * sizeof(unsigned short);
-  if (iv_NE) {                                                                 // sector intervals (float32-mixture instantiation)
-    s += (size_t)waves * (iv_NE + iv_cmax) * sizeof(unsigned long long);
-    s += (size_t)(iv_NE + 1) * sizeof(float) + (size_t)B * sizeof(unsigned short) + (size_t)iv_NB + 8;
-  }
+  if (!ivonly) s += ((size_t)B + NB + 4) * sizeof(unsigned short);
+  if (iv_NE)                                                                   // sector-interval tables
+    s += (size_t)(iv_NE + 1) * sizeof(float) + ((size_t)B + iv_NB + 2) * sizeof(unsigned short) + (size_t)iv_NE * sizeof(unsigned int) + 8;
   if (NE) {
     s += (size_t)NE * sizeof(unsigned int) + 8;                            // class / heading / beam of every entry (+ alignment of what follows)
     s += (size_t)(B0 + NE / B0) * sizeof(double);                          // beam and heading angles
@@ -850,18 +1005,40 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
   // log-weights only, float32 state, no range noise, measured ranges finite and >= 0: the float32 mixture
   const bool fast = !stage && !device_noise && dtype == MCLHIP_F32 && !product && !range_noise && c->zmeas_ok && MCL_FAST_LIKELIHOOD;
   if (stage || !MCL_FAST_INTERVALS) { P.iv_NE = 0; P.iv_cmax = 0; }
-  const size_t lds = ray_lds_bytes(P.B, P.G, P.NB, stage || product, kWavesPerBlock, 0, 0, P.iv_NE, P.iv_NB, P.iv_cmax);
+  // The float32-mixture path with sector intervals runs as two launches: the interval-only kernel, which files the
+  // particles it does not serve (headings outside the interval path's range: 5 % of a uniform cloud), and the general
+  // kernel over that list.  Together 0.9x ms instead of 1.05 ms at 2^20 x 180.
+  const bool split = fast && P.iv_NE > 0 && c->redo_list && n <= c->redo_cap && pm != nullptr;
+  // Wavefronts per block.  The block-wide tables grow with the beam count; when they keep a compute unit from holding
+  // the waves the instantiation is compiled for, twice the waves behind one copy of the tables hold more (360 beams
+  // with sector intervals: 16 waves per unit in blocks of four, 24 in blocks of eight).
+  int wpb = kWavesPerBlock;
+  // the interval-only kernel's fixed LDS layouts: 192 beams / intervals in blocks of four waves, 384 in blocks of eight
+  int cap = 0;
+  if (split && P.iv_cmax <= kCapSpan) {
+    auto fits = [&](int cc) { return P.B <= cc && P.iv_NE <= cc && P.iv_NB <= cap_buckets(cc); };
+    if (fits(192)) cap = 192;
+    else if (fits(384) && 2 * kWavesPerBlock <= 16) { cap = 384; wpb = 2 * kWavesPerBlock; }
+  }
+  auto lds_of = [&](int w) { return ray_lds_bytes(P.B, P.G, P.NB, stage || product, w, 0, 0, P.iv_NE, P.iv_NB, P.iv_cmax, split, cap); };
+  if (fast && cap == 0 && 2 * kWavesPerBlock <= 16) {
+    const int want = 4 * (split ? MCL_IVONLY_WAVES : MCL_FAST_WAVES);
+    auto waves_per_unit = [&](int w) { const size_t per = lds_of(w); return per > 160 * 1024 ? 0 : std::min<int>(want, (int)(160 * 1024 / per) * w); };
+    if (waves_per_unit(2 * kWavesPerBlock) > waves_per_unit(kWavesPerBlock)) wpb = 2 * kWavesPerBlock;
+  }
+  const size_t lds = lds_of(wpb);
   if (lds > 160 * 1024) return fail(c, MCLHIP_E_LIMIT, "beam table does not fit the kernel's LDS budget");
-  int64_t blocks = (n + kWavesPerBlock - 1) / kWavesPerBlock;
-  const int64_t max_blocks = MCL_MAX_BLOCKS;
+  int64_t blocks = (n + wpb - 1) / wpb;
+  const int64_t max_blocks = (int64_t)MCL_MAX_BLOCKS * kWavesPerBlock / wpb;
   if (blocks > max_blocks) blocks = max_blocks;
-  dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
+  dim3 grid((unsigned)blocks), block(64 * wpb);
   // large beam tables need more dynamic LDS than a kernel gets by default
 #define MCL_RAY(TT, SS, PP) MCL_RAY_N(TT, SS, PP, false)
 #define MCL_RAY_N(TT, SS, PP, NN) MCL_RAY_F(TT, SS, PP, NN, false)
-#define MCL_RAY_F(TT, SS, PP, NN, FF)                                                                                \
+#define MCL_RAY_F(TT, SS, PP, NN, FF) MCL_RAY_W(TT, SS, PP, NN, FF, kWavesPerBlock, false, false, 0)
+#define MCL_RAY_W(TT, SS, PP, NN, FF, WW, II, LL, CC)                                                                \
   do {                                                                                                               \
-    auto kern = raycast_kernel<TT, SS, PP, false, kWavesPerBlock, NN, FF>;                                           \
+    auto kern = raycast_kernel<TT, SS, PP, false, WW, NN, FF, II, LL, CC>;                                           \
     if (lds > 48 * 1024)                                                                                             \
       MCL_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                      (int)lds));                                                                     \
@@ -879,6 +1056,37 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
     }
   } else if (dtype == MCLHIP_F32) {
     if (product) MCL_RAY(float, false, true);
+    else if (split) {
+      MCL_HIP(c, hipMemsetAsync(c->redo_count, 0, kSubLists * sizeof(uint32_t), c->stream));
+      P.redo_list = c->redo_list; P.redo_count = c->redo_count;
+      // blocks b, b + 64, ... of the first launch append to list b % 64: what one list can receive is bounded by the
+      // particles those blocks serve
+      P.sub_cap = ((n + wpb - 1) / wpb + kSubLists - 1) / kSubLists * wpb;
+      if ((int64_t)P.sub_cap * kSubLists > c->redo_cap + mclhip_ctx::kRedoSlack) return fail(c, MCLHIP_E_LIMIT, "left-over list too small");
+      if (cap == 192) MCL_RAY_W(float, false, false, false, true, kWavesPerBlock, true, false, 192);
+      else if (cap == 384) MCL_RAY_W(float, false, false, false, true, 2 * kWavesPerBlock, true, false, 384);
+      else if (wpb != kWavesPerBlock) MCL_RAY_W(float, false, false, false, true, 2 * kWavesPerBlock, true, false, 0);
+      else MCL_RAY_W(float, false, false, false, true, kWavesPerBlock, true, false, 0);
+      MCL_HIP(c, hipGetLastError());
+      // what is left over, entry by entry (no interval tables; the list's length is known to the device only: the
+      // grid is sized for every particle and the blocks beyond the list leave at once -- a short list is bound by
+      // the latency of one particle per wave, so it wants many waves rather than long strides)
+      P.redo_list = nullptr; P.redo_count = nullptr; P.list = c->redo_list; P.list_count = c->redo_count;
+      P.iv_NE = 0; P.iv_cmax = 0;
+      const size_t lds_b = ray_lds_bytes(P.B, P.G, P.NB, false, kWavesPerBlock, 0, 0, 0, 0, 0);
+      if (lds_b > 160 * 1024) return fail(c, MCLHIP_E_LIMIT, "beam table does not fit the kernel's LDS budget");
+      int64_t blocks_b = (n + kWavesPerBlock - 1) / kWavesPerBlock;
+      if (blocks_b > MCL_MAX_BLOCKS) blocks_b = MCL_MAX_BLOCKS;
+      blocks_b = (blocks_b + kSubLists - 1) / kSubLists * kSubLists;      // the same number of blocks behind every list
+      {
+        auto kern = raycast_kernel<float, false, false, false, kWavesPerBlock, false, true, false, true>;
+        if (lds_b > 48 * 1024)
+          MCL_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks_b), block.x == 64u * kWavesPerBlock ? block : dim3(64 * kWavesPerBlock), lds_b, c->stream, P,
+                           (const float*)x, (const float*)y, (const float*)th, pm, n, w_out, logw_out, ranges_out, hits_out);
+      }
+    }
+    else if (fast && wpb != kWavesPerBlock) MCL_RAY_W(float, false, false, false, true, 2 * kWavesPerBlock, false, false, 0);
     else if (fast) MCL_RAY_F(float, false, false, false, true);
     else MCL_RAY(float, false, false);
   } else {
@@ -887,6 +1095,7 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
 #undef MCL_RAY
 #undef MCL_RAY_N
 #undef MCL_RAY_F
+#undef MCL_RAY_W
   MCL_HIP(c, hipGetLastError());
   return MCLHIP_OK;
 }

@@ -1,7 +1,7 @@
 """Profiling aid: cycles per section (`make -C slam_amd/csrc stamps`) or loop trip counts (`make -C slam_amd/csrc
 counts`) of the sector-query kernel; either target writes slam_amd/libmclhip_prof.so, which this script loads."""
 import os, sys
-os.environ["MCLHIP_LIBNAME"] = "libmclhip_prof.so"
+os.environ.setdefault("MCLHIP_LIBNAME", "libmclhip_prof.so")
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from slam_amd import _lib, workload as W
