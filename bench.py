@@ -176,7 +176,9 @@ def roofline(args, M, B, ray_ms, n_ray, copy_gbs):
     mix = profiled_mix(args)
     peak = SIMDS * PEAK_CLOCK_GHZ                       # G SIMD issue cycles per second
     out = {"bound": "valu", "achieved": None, "peak": peak, "unit": "G SIMD issue-cycles/s", "frac": None, "traffic": None,
-           "kernel": "raycast_kernel (sector query + beam likelihood)", "kernel_ms": ray_ms, "launches": n_ray,
+           "kernel": "raycast_kernel (sector query + beam likelihood; where the query runs as two launches, the first: "
+                     "the interval-only instantiation, which serves all particles but the few per cent whose heading lies "
+                     "outside the sector-interval path's range)", "kernel_ms": ray_ms, "launches": n_ray,
            "peak_is": "%d SIMD-32 x %.1f GHz" % (SIMDS, PEAK_CLOCK_GHZ),
            "algorithmic_bytes_per_eval": ALGO_BYTES_PER_EVAL,
            "algorithmic_bytes_per_launch": ALGO_BYTES_PER_EVAL * float(M) * B,
@@ -190,6 +192,9 @@ def roofline(args, M, B, ray_ms, n_ray, copy_gbs):
         out["valu_wave_instructions_per_launch"] = mix["valu_wave_instructions_per_launch"]
         out["valu_active_cycles_per_launch_hw"] = mix["hardware_valu_active_cycles_per_launch"]
         out["frac_hw_valu_active"] = mix["hardware_valu_active_cycles_per_launch"] / sec / 1e9 / peak
+        out["frac_hw_valu_active_is"] = ("SQ_ACTIVE_INST_VALU x 4 over SIMD cycles (rocprof's VALUBusy): counted per wave in "
+                                         "quad-cycles, it passes 1 when the vector pipeline is saturated with two-cycle "
+                                         "instructions; the priced fraction above is the one to hold the kernel to")
         out["traffic"] = mix["hbm_bytes_per_launch"]
         out["traffic_unit"] = "HBM bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, %s)" % mix["file"]
         if mix["hbm_bytes_per_launch"]:
@@ -317,6 +322,7 @@ def main():
     fence()
     n_mot, ms_mot = ctx.timing_get(1)
     n_res, ms_res = ctx.timing_get(2)
+    n_left, ms_left = ctx.timing_get(5)      # the sector query's second launch (particles the first left over), if any
     ctx.timing_enable(False)
 
     if rank == 0:
@@ -350,7 +356,8 @@ def main():
                           "host_reads_per_step": 1 if filt.device_path else "host-combined: about 13",
                           "note": "only rows that some position draws travel (48 B each)"}
                          if filt.collective else None),
-            "kernel_ms": {"raycast": ray_ms, "motion": ms_mot / max(n_mot, 1),
+            "kernel_ms": {"raycast": ray_ms, "raycast_leftover_launch": (ms_left / n_left) if n_left else None,
+                          "motion": ms_mot / max(n_mot, 1),
                           "normalise+resample+gather": ms_res / max(n_res, 1)},
         }
         if world == 1 and a.cpu_particles > 0:

@@ -466,9 +466,11 @@ int mclhip_fs_dshard_unpack(mclhip_ctx* ctx, const void* d_rows, const void* d_f
 /* Measurement ------------------------------------------------------------ */
 
 /* Per-kernel timing with HIP events on the context's own stream.
- * which: 0 = sector-query + likelihood kernel, 1 = motion kernel,
+ * which: 0 = sector-query + likelihood kernel (where the query runs as two launches: the first, which serves the
+ *            particles of the sector-interval path), 1 = motion kernel,
  *        2 = normalise + resample + gather kernels together,
- *        3 = grid prediction, 4 = grid update.
+ *        3 = grid prediction, 4 = grid update,
+ *        5 = the sector query's second launch (the particles the first left over), only with on = 1.
  * on: 0 off, 1 every group, 2 the sector-query kernel only (two events per step instead of six: an event between
  * two kernels costs a few microseconds of idle GPU).  Enabling resets the accumulators. */
 int mclhip_timing_enable(mclhip_ctx* ctx, int on);

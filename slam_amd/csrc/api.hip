@@ -249,6 +249,10 @@ static MotionParams make_motion_params(const mclhip_ctx* c, double v, double ome
   return mp;
 }
 
+// the same for code outside this file (the sector query marks its own launches)
+void timing_begin(mclhip_ctx* c, int which) { span_begin(c, c->spans, which); }
+void timing_end(mclhip_ctx* c) { span_end(c, c->spans); }
+
 static int need(mclhip_ctx* c, bool map, bool sensor, bool particles) {
   if (map && !c->obst) return fail(c, MCLHIP_E_STATE, "no map: call mclhip_set_map first");
   if (sensor && c->B == 0) return fail(c, MCLHIP_E_STATE, "no sensor: call mclhip_set_sensor first");
@@ -268,11 +272,10 @@ static int enqueue_sample(mclhip_ctx* c, double v, double omega, double dt, cons
   span_begin(c, spans, 1);
   MCL_TRY(launch_motion(c, c->px[a], c->py[a], c->pth[a], c->pm, c->M, mp, c->noise, c->dtype));
   span_end(c, spans);
-  span_begin(c, spans, 0);
+  // (timed inside: group 0 around its kernel, or around the first of its two kernels and group 5 around the second)
   // the raw product is only formed when somebody will read it: it costs one dependent multiply per beam
   MCL_TRY(launch_raycast(c, c->px[a], c->py[a], c->pth[a], c->pm, c->M, c->dtype, want_product ? c->w[a] : nullptr,
                          c->logw, nullptr, nullptr, d_range_noise, rn_sigma, seed));
-  span_end(c, spans);
   return MCLHIP_OK;
 }
 
@@ -1352,7 +1355,7 @@ int mclhip_shard_unpack_drawn(mclhip_ctx* c, const void* rows, int64_t L, double
 int mclhip_timing_enable(mclhip_ctx* c, int on) {
   if (!c) return MCLHIP_E_ARG;
   c->timing = on == 2 ? 2 : (on != 0 ? 1 : 0);
-  for (int i = 0; i < 5; ++i) { c->t_launch[i] = 0; c->t_ms[i] = 0; }
+  for (int i = 0; i < 6; ++i) { c->t_launch[i] = 0; c->t_ms[i] = 0; }
   return MCLHIP_OK;
 }
 
@@ -1364,7 +1367,7 @@ int mclhip_timing_get(mclhip_ctx* c, int which, int64_t* launches, double* total
     if (total_ms) *total_ms = (double)v;
     return MCLHIP_OK;
   }
-  if (!c || which < 0 || which > 4) return MCLHIP_E_ARG;
+  if (!c || which < 0 || which > 5) return MCLHIP_E_ARG;
   if (launches) *launches = c->t_launch[which];
   if (total_ms) *total_ms = c->t_ms[which];
   return MCLHIP_OK;

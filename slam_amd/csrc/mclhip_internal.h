@@ -239,8 +239,8 @@ struct mclhip_ctx {
   // timing
   int timing = 0;            // 0 off, 1 every kernel group, 2 the sector-query kernel only
   bool span_open = false;    // the last span_begin recorded an event
-  int64_t t_launch[5] = {0, 0, 0, 0, 0};
-  double t_ms[5] = {0, 0, 0, 0, 0};
+  int64_t t_launch[6] = {0, 0, 0, 0, 0, 0};
+  double t_ms[6] = {0, 0, 0, 0, 0, 0};
   struct Span { hipEvent_t a, b; int which; };
   std::vector<Span> spans;   // event pairs recorded but not yet read back
 };
@@ -275,6 +275,9 @@ int launch_restore(mclhip_ctx* c, void* x, void* y, void* th, double* w, const v
                    const double* sw, int64_t n, int dtype);
 int launch_init_particles(mclhip_ctx* c, void* x, void* y, void* th, int64_t n, const MotionParams& mp, int gaussian,
                           double ext_x, double ext_y, const double* x0, uint64_t seed, uint32_t* d_failures);
+// timing events of group `which` around what is launched between the two calls (no-ops unless timing is enabled)
+void timing_begin(mclhip_ctx* c, int which);
+void timing_end(mclhip_ctx* c);
 int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, const uint8_t* pm, int64_t n,
                    int dtype, double* w_out, double* logw_out, double* ranges_out, int32_t* hits_out,
                    const double* range_noise = nullptr, double rn_sigma = 0.0, uint64_t rn_seed = 0);

@@ -289,7 +289,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
   const uint32_t* nbr_off = P.nbr_off;
   const uint32_t* nbr_cells = P.nbr_cells;
   int ETW = P.ETW, ETH = P.ETH, rtx = P.rtx, rty = P.rty;
-  asm volatile("" : "+s"(nbr_off), "+s"(nbr_cells), "+s"(ETW), "+s"(ETH), "+s"(rtx), "+s"(rty));
+  if constexpr (!GRID) asm volatile("" : "+s"(nbr_off), "+s"(nbr_cells), "+s"(ETW), "+s"(ETH), "+s"(rtx), "+s"(rty));
   // likewise these arguments.  (Not the pose pointers: one that has gone through this is no longer known to point to
   // read-only memory, its loads become vector loads and the pose lives in vector registers -- measured slower.)
   asm volatile("" : "+s"(logw_out), "+s"(n));
@@ -374,7 +374,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
     // the lane index is made opaque once per particle: comparisons against it are then formed where they are used
     // (one instruction) instead of being kept as 64-bit masks in scalar registers that spill
     int lane = lane0;
-    asm volatile("" : "+v"(lane));
+    if constexpr (!GRID) asm volatile("" : "+v"(lane));
     const double x = (double)nx, y = (double)ny, th = (double)nth;
     const bool on_free = npm != 0;
     // headings for which the reference's predicate is the circular one take the interval path (wave-uniform); a
@@ -1045,6 +1045,7 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
     hipLaunchKernelGGL(kern, grid, block, lds, c->stream, P, (const TT*)x, (const TT*)y, (const TT*)th, pm, n, w_out, \
                        logw_out, ranges_out, hits_out);                                                              \
   } while (0)
+  if (!stage && !split) timing_begin(c, 0);
   if (stage) {
     if (dtype != MCLHIP_F64) return fail(c, MCLHIP_E_ARG, "stage query takes float64 poses");
     MCL_RAY(double, true, false);
@@ -1059,6 +1060,7 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
     else if (split) {
       MCL_HIP(c, hipMemsetAsync(c->redo_count, 0, kSubLists * sizeof(uint32_t), c->stream));
       P.redo_list = c->redo_list; P.redo_count = c->redo_count;
+      timing_begin(c, 0);
       // blocks b, b + 64, ... of the first launch append to list b % 64: what one list can receive is bounded by the
       // particles those blocks serve
       P.sub_cap = ((n + wpb - 1) / wpb + kSubLists - 1) / kSubLists * wpb;
@@ -1068,6 +1070,8 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
       else if (wpb != kWavesPerBlock) MCL_RAY_W(float, false, false, false, true, 2 * kWavesPerBlock, true, false, 0);
       else MCL_RAY_W(float, false, false, false, true, kWavesPerBlock, true, false, 0);
       MCL_HIP(c, hipGetLastError());
+      timing_end(c);
+      timing_begin(c, 5);
       // what is left over, entry by entry (no interval tables; the list's length is known to the device only: the
       // grid is sized for every particle and the blocks beyond the list leave at once -- a short list is bound by
       // the latency of one particle per wave, so it wants many waves rather than long strides)
@@ -1085,6 +1089,7 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks_b), block.x == 64u * kWavesPerBlock ? block : dim3(64 * kWavesPerBlock), lds_b, c->stream, P,
                            (const float*)x, (const float*)y, (const float*)th, pm, n, w_out, logw_out, ranges_out, hits_out);
       }
+      timing_end(c);
     }
     else if (fast && wpb != kWavesPerBlock) MCL_RAY_W(float, false, false, false, true, 2 * kWavesPerBlock, false, false, 0);
     else if (fast) MCL_RAY_F(float, false, false, false, true);
@@ -1096,6 +1101,7 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
 #undef MCL_RAY_N
 #undef MCL_RAY_F
 #undef MCL_RAY_W
+  if (!stage && !split) timing_end(c);
   MCL_HIP(c, hipGetLastError());
   return MCLHIP_OK;
 }

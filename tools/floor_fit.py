@@ -9,13 +9,14 @@ rows = []
 for log in sorted(glob.glob(os.path.join(src, "fit_*.log"))):
     m = re.search(r"cells_in_range ([\d.]+) occupancy ([\d.]+) beams (\d+)", open(log).read())
     d = log[:-4]
-    vals = []
+    vals = {}          # per instantiation (the query may run as two launches per step: their instructions add up)
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if "raycast_kernel<float, false, false, false" in r["Kernel_Name"] and r["Counter_Name"] == "SQ_INSTS_VALU":
-                vals.append(float(r["Counter_Value"]))
+                vals.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
     rows.append({"cells_in_range": float(m.group(1)), "occupancy": float(m.group(2)), "beams": int(m.group(3)),
-                 "valu_wave_instructions_per_particle": float(np.mean(vals)) / (1 << 20), "launches": len(vals)})
+                 "valu_wave_instructions_per_particle": sum(float(np.mean(v)) for v in vals.values()) / (1 << 20),
+                 "launches": {k[:90]: len(v) for k, v in vals.items()}})
 A = np.array([[1.0, r["cells_in_range"], r["beams"]] for r in rows])
 y = np.array([r["valu_wave_instructions_per_particle"] for r in rows])
 coef, res, _, _ = np.linalg.lstsq(A, y, rcond=None)
