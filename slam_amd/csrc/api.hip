@@ -569,7 +569,10 @@ int mcl::set_sensor_table(mclhip_ctx* c, const double* tab_rad, int B, double z_
         MCL_HIP(c, hipMemcpy(c->iv_beam, beam.data(), B * sizeof(uint16_t), hipMemcpyHostToDevice));
         MCL_HIP(c, hipMemcpy(c->iv_lut, ilut.data(), NBI * sizeof(uint16_t), hipMemcpyHostToDevice));
         c->iv_NE = NE; c->iv_NB = NBI; c->iv_cmax = cmax; c->iv_cmin = cmin; c->iv_origin = origin;
-        c->iv_th_hi = two_pi - 2.0 * half - 1e-3;
+        // headings for which no sector leaves the range the reference recognises: the highest beam angle + heading +
+        // half-angle stays below two turns, the lowest beam angle + heading - half-angle above minus one turn
+        // (kept as one symmetric bound: the kernel holds one constant for it)
+        c->iv_th_hi = std::min(2.0 * two_pi - half - c->ts_max, two_pi - half + c->ts_min) - 1e-3;
       }
     }
   }

@@ -66,9 +66,10 @@ struct RayParams {
                                // exactly these beams with the reference's float64 predicate.
   double iv_origin;            // angle of edge 0 (the lowest sector edge)
   double iv_th_hi;             // headings in [-iv_th_hi, iv_th_hi] take this path: there the reference's predicate (one turn
-                               // of slack either way, mc_localization.py:148-149) is the circular one -- beam angle + heading
-                               // stays within (-2 pi + half-angle, 4 pi - half-angle), and a bearing in [0, 2 pi) is then
-                               // never two turns away from it
+                               // of slack either way, mc_localization.py:148-149) is the circular one -- every beam angle +
+                               // heading stays within (-2 pi + half-angle, 4 pi - half-angle), and a bearing in [0, 2 pi) is
+                               // then never two turns away from it.  For beams over [0, 358] degrees with 5-degree sectors:
+                               // headings up to 355 degrees either way.
   // Two launches of the float32-mixture path: the interval-only kernel files the particles it does not serve ...
   int32_t* redo_list;          // 64 lists of sub_cap places each (blocks b, b + 64, ... append to list b % 64)
   uint32_t* redo_count;        // [64], zero before the launch

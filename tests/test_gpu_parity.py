@@ -258,8 +258,9 @@ def test_f32_state_mode(name):
 @pytest.mark.parametrize("beams", ["even180", "even360", "reference13", "uneven", "wide_repeated", "narrow", "single"])
 def test_sector_intervals_against_the_oracle(beams):
     """The float32 instantiation files a cell under the sector interval its bearing falls in (one minimum per interval,
-    a beam's range = the smallest of the intervals its sector spans) when the heading lies in [0, 2 pi - 2 half-angles);
-    other headings, and bearings within rounding of a sector edge, go beam by beam.  Headings on both sides of the two
+    a beam's range = the smallest of the intervals its sector spans) when no beam angle + heading leaves the range in
+    which the reference recognises a turn (mc_localization.py:148-149); other headings go beam by beam, bearings within
+    rounding of a sector edge are decided in float64.  Headings on both sides of the two
     limits, negative ones and ones past a full turn, evenly and unevenly spaced beam sets (overlapping sectors, disjoint
     sectors, sectors that share an edge): log-weights against the oracle's, which follows mc_localization.py:116-171."""
     from slam_amd import workload as W
@@ -284,8 +285,12 @@ def test_sector_intervals_against_the_oracle(beams):
     M = 1500
     X = W.uniform_particles(grid, M, seed=3)
     th = rng.uniform(0.0, 2 * np.pi, M)
-    lim = 2 * np.pi - 2 * half - 1e-3
-    th[:200] = lim + rng.uniform(-2e-3, 2e-3, 200)            # around the upper limit of the interval path
+    arad = np.asarray(angles, float) * np.pi / 180.0
+    lim_hi = min(4 * np.pi - half - arad.max(), 2 * np.pi - half + arad.min()) - 1e-3   # the interval path serves
+    lim_lo = -lim_hi                                                                      # headings in [-lim_hi, lim_hi]
+    th[:80] = lim_hi + rng.uniform(-2e-3, 2e-3, 80)           # around the upper limit of the interval path
+    th[80:160] = lim_lo + rng.uniform(-2e-3, 2e-3, 80)        # around the lower limit
+    th[160:200] = 2 * np.pi - 2 * half + rng.uniform(-2e-3, 2e-3, 40)   # where the highest sector starts to pass two turns
     th[200:400] = rng.uniform(-1e-3, 1e-3, 200)               # around zero
     th[400:500] = rng.uniform(-7.0, 0.0, 100)                 # negative, some below one turn
     th[500:600] = rng.uniform(2 * np.pi, 13.5, 100)           # past one and two turns
