@@ -23,9 +23,19 @@
 // evaluated and the reference predicate applied literally.  Each (cell, beam)
 // match is a 64-bit LDS atomic min on the bit pattern of r2 (non-negative
 // doubles order like unsigned integers).  The beam tables are staged in LDS
-// once per block.  The kernel is VALU-bound (about 75 % VALU-busy at three
-// waves per SIMD); its HBM traffic is the neighbourhood slices, ~1.4 KB per
-// particle.
+// once per block.  The kernel is bound by vector-instruction issue; its HBM
+// traffic is the neighbourhood slices, ~1 KB per particle.
+//
+// Sector intervals (beam sets that allow them; not the staged query, not the
+// histogram filter): the sector edges cut the circle into intervals inside
+// which the set of sectors that hold a bearing does not change, a cell files
+// ONE minimum under its interval, a beam reads the few intervals its sector
+// spans, and a cell within rounding of an edge is decided in float64 against
+// the one sector that ends and the one that starts there.  The float32
+// throughput path runs as two launches: an instantiation that holds nothing
+// but the interval path (IVONLY), and the general one over the particles the
+// first leaves (headings for which the reference's one-turn predicate is not
+// the circular one).
 //
 // Compiled with -ffp-contract=off.
 #include <algorithm>
