@@ -707,13 +707,24 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
           double best = P.r2max;
           // (the plain instruction: nothing here is a NaN, so the library minimum's quieting of operands is not needed)
           auto lower = [](double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
-          if (P.iv_cmin == P.iv_cmax) {                               // every sector spans as many intervals (evenly spaced beams)
-            for (int j = 0; j < P.iv_cmax; ++j) best = lower(best, __longlong_as_double((long long)run[j]));
-          } else {
-            for (int j = 0; j < P.iv_cmax; ++j) {
-              const double v = __longlong_as_double((long long)run[j]);
-              best = lower(best, j < cnt ? v : best);
+          // five intervals at a time, their reads in flight together (a read-minimum chain per interval: 0.845 -> 0.826 ms
+          // at 180 beams, 1.43 -> 1.29 ms at 360; a branch of its own for exactly five measured 0.807 alone and 0.877
+          // beside this loop -- the register allocation of this kernel turns on such things), the rest one by one; `uniform`: every sector spans as many intervals (evenly spaced beams)
+          const bool uniform = P.iv_cmin == P.iv_cmax;
+          int j = 0;
+          for (; j + 5 <= P.iv_cmax; j += 5) {
+            double v0 = __longlong_as_double((long long)run[j]), v1 = __longlong_as_double((long long)run[j + 1]),
+                   v2 = __longlong_as_double((long long)run[j + 2]), v3 = __longlong_as_double((long long)run[j + 3]),
+                   v4 = __longlong_as_double((long long)run[j + 4]);
+            if (!uniform) {
+              v0 = j < cnt ? v0 : best; v1 = j + 1 < cnt ? v1 : best; v2 = j + 2 < cnt ? v2 : best;
+              v3 = j + 3 < cnt ? v3 : best; v4 = j + 4 < cnt ? v4 : best;
             }
+            best = lower(best, lower(lower(lower(v0, v1), lower(v2, v3)), v4));
+          }
+          for (; j < P.iv_cmax; ++j) {
+            const double v = __longlong_as_double((long long)run[j]);
+            best = lower(best, (uniform || j < cnt) ? v : best);
           }
           rb = (unsigned long long)__double_as_longlong(best);
         }
