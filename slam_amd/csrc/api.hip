@@ -503,7 +503,7 @@ int mcl::set_sensor_table(mclhip_ctx* c, const double* tab_rad, int B, double z_
   {
     // Sector intervals.  Available when every beam angle lies in [0, 2 pi) and the sectors are proper arcs; edges that
     // agree to 1e-9 rad count as one (a bearing that close to either is decided by the exact test anyway).
-    c->iv_NE = 0; c->iv_NB = 0; c->iv_cmax = 0; c->iv_cmin = 0;
+    c->iv_NE = 0; c->iv_NB = 0; c->iv_cmax = 0; c->iv_cmin = 0; c->iv_uniform = false;
     const bool usable = c->ts_min >= 0.0 && c->ts_max < two_pi && half > 16.0 * kEdgeEps && half < 0.5 * M_PI;
     if (usable) {
       const double origin = c->ts_min - half;
@@ -569,6 +569,10 @@ int mcl::set_sensor_table(mclhip_ctx* c, const double* tab_rad, int B, double z_
         MCL_HIP(c, hipMemcpy(c->iv_beam, beam.data(), B * sizeof(uint16_t), hipMemcpyHostToDevice));
         MCL_HIP(c, hipMemcpy(c->iv_lut, ilut.data(), NBI * sizeof(uint16_t), hipMemcpyHostToDevice));
         c->iv_NE = NE; c->iv_NB = NBI; c->iv_cmax = cmax; c->iv_cmin = cmin; c->iv_origin = origin;
+        // equally wide intervals (evenly spaced beams): a kernel variant finds a bearing's interval by arithmetic
+        c->iv_uniform = true;
+        for (int m = 0; m < NE; ++m)
+          if (std::fabs(edge[m] - two_pi * m / NE) > 1e-9) c->iv_uniform = false;
         // headings for which no sector leaves the range the reference recognises: the highest beam angle + heading +
         // half-angle stays below two turns, the lowest beam angle + heading - half-angle above minus one turn
         // (kept as one symmetric bound: the kernel holds one constant for it)

@@ -149,7 +149,7 @@ struct mclhip_ctx {
   uint16_t* inv_perm = nullptr;
   uint16_t* lut = nullptr;
   float* iv_edge = nullptr; uint16_t* iv_beam = nullptr; uint16_t* iv_lut = nullptr; uint32_t* iv_ends = nullptr;   // sector intervals (see RayParams)
-  int iv_NE = 0, iv_NB = 0, iv_cmax = 0, iv_cmin = 0; double iv_origin = 0.0, iv_th_hi = 0.0;
+  int iv_NE = 0, iv_NB = 0, iv_cmax = 0, iv_cmin = 0; double iv_origin = 0.0, iv_th_hi = 0.0; bool iv_uniform = false;   // (uniform: the intervals are equally wide)
   float* relx = nullptr;
   int G = 0;
   double ext_min = 0;

@@ -208,8 +208,10 @@ __device__ __attribute__((noinline)) double slow_log(double v) { return log(v); 
 // CAP (with IVONLY): the LDS arrays are laid out for CAP beams, CAP intervals, sectors of at most kCapSpan intervals
 // and a look-up of cap_buckets(CAP) entries, whatever the table at hand needs: every address is then a compile-time
 // offset from the block's or the wave's base instead of a value kept in a scalar register.
+// UNIF (with IVONLY): the intervals are equally wide (evenly spaced beams): a bearing's interval and its edges are
+// arithmetic, not two dependent LDS reads.
 template <typename T, bool STAGE, bool PRODUCT, bool GRID = false, int WPB = kWavesPerBlock, bool RNOISE = false,
-          bool FAST = false, bool IVONLY = false, bool LISTED = false, int CAP = 0>
+          bool FAST = false, bool IVONLY = false, bool LISTED = false, int CAP = 0, bool UNIF = false>
 // (waves per SIMD as a closed range: with only a lower bound the compiler budgets scalar registers for the ten waves
 // a small vector-register count would allow -- 80 instead of 96 -- and spills the rest into vector lanes)
 #define MCL_RAY_OCC(T, GRID, WPB, FAST, IVONLY) (GRID ? WPB / 4 : (IVONLY ? MCL_IVONLY_WAVES : (FAST ? MCL_FAST_WAVES : (sizeof(T) == 4 ? MCL_RAY_WAVES : 4))))
@@ -335,7 +337,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
   if (IVONLY && lane0 == 0) filed_cnt[0] = 0u;
   unsigned long long* const imin = rmin;                               // the same array read as minima per sector interval
   const float iv_originf = (float)P.iv_origin, iv_inv_bwf = (float)((double)P.iv_NB / kTwoPi), iv_th_hif = (float)P.iv_th_hi;
-  const float iv_nearf = (float)kEdgeEps + 3e-6f;     // closer than this to a sector edge, float32 does not decide
+  const float iv_nearf = (float)kEdgeEps + (UNIF ? 4e-6f : 3e-6f);     // closer than this to a sector edge, float32 does not decide
+  const float iv_wf = (float)(kTwoPi / (double)(P.iv_NE > 0 ? P.iv_NE : 1)), iv_inv_wf = (float)((double)P.iv_NE / kTwoPi);   // UNIF: interval width
 
   const unsigned long long r2max_bits = (unsigned long long)__double_as_longlong(P.r2max);
   const float disk_r = (float)(P.z_max * (1.0 + 1e-5) + 0.02 * (P.res_x < P.res_y ? P.res_x : P.res_y));
@@ -430,13 +433,24 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
           // bearing within rounding of a sector edge goes through the beam-by-beam test below.
           float a = (aaf - thf) - iv_originf;                         // in (-4 pi, 5 pi) for the headings of this path
           a = fmaf(-6.2831853071795865f, floorf(a * 0.15915494309189535f), a);   // [0, 2 pi) up to rounding; the ends are edges
-          int bkt = (int)(a * iv_inv_bwf);
-          bkt = bkt < 0 ? 0 : (bkt > P.iv_NB - 1 ? P.iv_NB - 1 : bkt);
-          int m = s_ivlut[bkt];                 // a bucket is a quarter of the average interval: at most one step as a rule
-          float e0 = s_ivedge[m], e1 = s_ivedge[m + 1];
-          if (e1 <= a && m + 1 < IVN) {
-            ++m; e0 = e1; e1 = s_ivedge[m + 1];
-            while (e1 <= a && m + 1 < IVN) { ++m; e0 = e1; e1 = s_ivedge[m + 1]; }
+          int m;
+          float e0, e1;
+          if constexpr (UNIF) {
+            // (the products differ from the table's float32 edges by an ulp at most: the band below allows for it, and a
+            // bearing that lands one interval off is within the band of the edge between the two, which is what counts)
+            m = (int)(a * iv_inv_wf);
+            m = m < 0 ? 0 : (m > IVN - 1 ? IVN - 1 : m);
+            e0 = (float)m * iv_wf;
+            e1 = e0 + iv_wf;
+          } else {
+            int bkt = (int)(a * iv_inv_bwf);
+            bkt = bkt < 0 ? 0 : (bkt > P.iv_NB - 1 ? P.iv_NB - 1 : bkt);
+            m = s_ivlut[bkt];                   // a bucket is half the average interval: at most a step or two
+            e0 = s_ivedge[m]; e1 = s_ivedge[m + 1];
+            if (e1 <= a && m + 1 < IVN) {
+              ++m; e0 = e1; e1 = s_ivedge[m + 1];
+              while (e1 <= a && m + 1 < IVN) { ++m; e0 = e1; e1 = s_ivedge[m + 1]; }
+            }
           }
           const bool at_lower = !(a - e0 >= iv_nearf);                              // also NaN
           const bool near_edge = at_lower || !(e1 - a >= iv_nearf);
@@ -1070,9 +1084,10 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
 #define MCL_RAY(TT, SS, PP) MCL_RAY_N(TT, SS, PP, false)
 #define MCL_RAY_N(TT, SS, PP, NN) MCL_RAY_F(TT, SS, PP, NN, false)
 #define MCL_RAY_F(TT, SS, PP, NN, FF) MCL_RAY_W(TT, SS, PP, NN, FF, kWavesPerBlock, false, false, 0)
-#define MCL_RAY_W(TT, SS, PP, NN, FF, WW, II, LL, CC)                                                                \
+#define MCL_RAY_W(TT, SS, PP, NN, FF, WW, II, LL, CC) MCL_RAY_U(TT, SS, PP, NN, FF, WW, II, LL, CC, false)
+#define MCL_RAY_U(TT, SS, PP, NN, FF, WW, II, LL, CC, UU)                                                              \
   do {                                                                                                               \
-    auto kern = raycast_kernel<TT, SS, PP, false, WW, NN, FF, II, LL, CC>;                                           \
+    auto kern = raycast_kernel<TT, SS, PP, false, WW, NN, FF, II, LL, CC, UU>;                                         \
     if (lds > 48 * 1024)                                                                                             \
       MCL_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                      (int)lds));                                                                     \
@@ -1099,7 +1114,9 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
       // particles those blocks serve
       P.sub_cap = ((n + wpb - 1) / wpb + kSubLists - 1) / kSubLists * wpb;
       if ((int64_t)P.sub_cap * kSubLists > c->redo_cap + mclhip_ctx::kRedoSlack) return fail(c, MCLHIP_E_LIMIT, "left-over list too small");
-      if (cap == 192) MCL_RAY_W(float, false, false, false, true, kWavesPerBlock, true, false, 192);
+      if (cap == 192 && c->iv_uniform) MCL_RAY_U(float, false, false, false, true, kWavesPerBlock, true, false, 192, true);
+      else if (cap == 384 && c->iv_uniform) MCL_RAY_U(float, false, false, false, true, 2 * kWavesPerBlock, true, false, 384, true);
+      else if (cap == 192) MCL_RAY_W(float, false, false, false, true, kWavesPerBlock, true, false, 192);
       else if (cap == 384) MCL_RAY_W(float, false, false, false, true, 2 * kWavesPerBlock, true, false, 384);
       else if (wpb != kWavesPerBlock) MCL_RAY_W(float, false, false, false, true, 2 * kWavesPerBlock, true, false, 0);
       else MCL_RAY_W(float, false, false, false, true, kWavesPerBlock, true, false, 0);
@@ -1135,6 +1152,7 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
 #undef MCL_RAY_N
 #undef MCL_RAY_F
 #undef MCL_RAY_W
+#undef MCL_RAY_U
   if (!stage && !split) timing_end(c);
   MCL_HIP(c, hipGetLastError());
   return MCLHIP_OK;
