@@ -396,6 +396,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
     const bool use_iv = IVK && IVN > 0 && !entry_by_entry && (float)th >= -iv_th_hif && (float)th <= iv_th_hif;
     entry_by_entry = false;
     bool lane_redo = false;
+    bool lane_parked = false;   // this lane has parked a cell
     // tile that holds the particle; poses far outside any map (or NaN) visit no tile
     // (a product instead of a division: an index off by one at an exact tile edge is covered by the
     // ring table's two cells of slack)
@@ -462,6 +463,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
             const unsigned int pos = atomicAdd(edge_cnt, 1u);
             if (pos < (unsigned int)kEdgeQueue) edgeq[pos] = ((unsigned long long)E << 32) | e;
             else lane_redo = true;
+            lane_parked = true;
           }
           hit = false;
         }
@@ -654,7 +656,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
         // interval above it the interior ones and the starting one: every outcome but one is a choice of these two
         // minima, and that one -- both refuse while interior sectors exist -- sends the particle through the
         // entry-by-entry test.
-        const int nq = __builtin_amdgcn_readfirstlane((int)edge_cnt[0]);
+        // (most particles park nothing: a flag kept in a register spares them the read of the count and its wait)
+        const int nq = __ballot(lane_parked) != 0ull ? __builtin_amdgcn_readfirstlane((int)edge_cnt[0]) : 0;
         if (nq > 0) {
           if (lane < nq && lane < kEdgeQueue) {
             const unsigned long long q = edgeq[lane];
