@@ -335,6 +335,9 @@ int mclhip_create(mclhip_ctx** out, int device, int dtype) {
   if (e == hipSuccess) e = hipMalloc((void**)&c->scal, 8 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&c->stamps, 16 * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMemset(c->stamps, 0, 16 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c->redo_hint, 64 * sizeof(uint32_t), hipHostMallocDefault);
+  if (e == hipSuccess) std::memset(c->redo_hint, 0, 64 * sizeof(uint32_t));
+  if (const char* m = std::getenv("MCLHIP_SPLIT")) c->split_mode = (m[0] == '0') ? 0 : (m[0] == '1' ? 1 : -1);
   if (e == hipSuccess) resolve_static_scratch(device);
   if (e != hipSuccess) {
     fail(nullptr, MCLHIP_E_HIP, std::string("context set-up failed: ") + hipGetErrorString(e));
@@ -359,6 +362,7 @@ void mclhip_destroy(mclhip_ctx* c) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (c->zpin) (void)hipHostFree(c->zpin);
+  if (c->redo_hint) (void)hipHostFree(c->redo_hint);
   for (int k = 0; k < mclhip_ctx::kZSlots; ++k)
     if (c->zev[k]) (void)hipEventDestroy(c->zev[k]);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);

@@ -172,6 +172,13 @@ struct mclhip_ctx {
   int64_t M = 0, cap = 0;
   int32_t* redo_list = nullptr; uint32_t* redo_count = nullptr; int64_t redo_cap = 0;   // particles the interval-only sector query left over
   static constexpr int64_t kRedoSlack = 64 * 16 * 2;   // the 64 lists are rounded up to whole blocks of waves
+  // How many particles the interval-only launch left over last time (page-locked host copy of the 64 counters, written
+  // by an asynchronous copy behind the second launch and read, without waiting, before the next query is enqueued --
+  // a hint, a step old): when most of the cloud is left over (headings outside the interval path's range) the query
+  // runs as one kernel, which serves such a cloud faster than two launches do, and probes again every eighth query.
+  uint32_t* redo_hint = nullptr;
+  int split_mode = -1;          // -1 by the hint, 0 never two launches, 1 always (environment MCLHIP_SPLIT at creation)
+  int64_t split_skipped = 0;
   void* px[2] = {nullptr, nullptr};
   void* py[2] = {nullptr, nullptr};
   void* pth[2] = {nullptr, nullptr};

@@ -1059,7 +1059,13 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
   // The float32-mixture path with sector intervals runs as two launches: the interval-only kernel, which files the
   // particles it does not serve (headings outside the interval path's range: 5 % of a uniform cloud), and the general
   // kernel over that list.  Together 0.9x ms instead of 1.05 ms at 2^20 x 180.
-  const bool split = fast && P.iv_NE > 0 && c->redo_list && n <= c->redo_cap && pm != nullptr;
+  bool split = fast && P.iv_NE > 0 && c->redo_list && n <= c->redo_cap && pm != nullptr && c->split_mode != 0;
+  if (split && c->split_mode < 0 && c->redo_hint) {
+    // last time's left-over count (a hint, see mclhip_ctx::redo_hint)
+    uint64_t left = 0;
+    for (int k = 0; k < kSubLists; ++k) left += reinterpret_cast<volatile uint32_t*>(c->redo_hint)[k];
+    if (left * 4 > (uint64_t)n && (++c->split_skipped % 8) != 0) split = false;
+  }
   // Wavefronts per block.  The block-wide tables grow with the beam count; when they keep a compute unit from holding
   // the waves the instantiation is compiled for, twice the waves behind one copy of the tables hold more (360 beams
   // with sector intervals: 16 waves per unit in blocks of four, 24 in blocks of eight).
@@ -1144,6 +1150,8 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
                            (const float*)x, (const float*)y, (const float*)th, pm, n, w_out, logw_out, ranges_out, hits_out);
       }
       timing_end(c);
+      if (c->redo_hint)
+        MCL_HIP(c, hipMemcpyAsync(c->redo_hint, c->redo_count, kSubLists * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     }
     else if (fast && wpb != kWavesPerBlock) MCL_RAY_W(float, false, false, false, true, 2 * kWavesPerBlock, false, false, 0);
     else if (fast) MCL_RAY_F(float, false, false, false, true);

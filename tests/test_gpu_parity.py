@@ -631,3 +631,39 @@ def test_fused_step_equals_the_separate_calls(dtype, mode):
             assert np.isfinite(total)
         a.close()
         b.close()
+
+
+def test_one_kernel_and_two_launch_sector_query_agree_bit_for_bit(monkeypatch):
+    """The float32 throughput path runs the sector query as two launches (interval-only kernel + the general kernel over
+    what it leaves) or, when most of the cloud lies outside the interval path's heading range, as the one kernel that
+    holds both paths (MCLHIP_SPLIT = 1 / 0 force either; read when a context is created).  Which one runs is a matter
+    of speed only: the log-weights are the same bits."""
+    from slam_amd import workload as W
+    L = _lib()
+    grid = W.synthetic_map(256)
+    rng = np.random.RandomState(9)
+    M = 20_011
+    X = W.uniform_particles(grid, M, seed=5)
+    th = rng.uniform(-6.5, 6.5, M)                       # a sixth outside the range (|heading| > 355 degrees and beyond)
+    th[:500] = np.round(rng.uniform(0, 72, 500)) * (5 * np.pi / 180.0)   # lattice headings: cells exactly on sector edges
+    X[:, 2] = th
+    X = X.astype(np.float32).astype(np.float64)
+    w4 = np.array([0.97, 0.005, 0.020, 0.005]); w4 /= w4.sum()
+    zero = np.zeros((M, 3, 12), np.int16)
+    got = {}
+    for mode in ("0", "1", "auto"):
+        if mode == "auto":
+            monkeypatch.delenv("MCLHIP_SPLIT", raising=False)
+        else:
+            monkeypatch.setenv("MCLHIP_SPLIT", mode)
+        ctx = L.Context(0, L.F32)
+        ctx.set_map(grid, W.RES, W.RES)
+        ctx.set_sensor(W.beam_angles(180), W.Z_MAX, 0.15, 1.0, w4, 5 * np.pi / 180.0)
+        z_meas = ctx.raycast(np.array([3.0, 4.5, 0.3]), want_hits=False)[0][0]
+        ctx.set_particles(X)
+        for _ in range(3):                                # (auto: the second and third query know the first one's count)
+            ctx.shard_sample(0.0, 1e-12, 0.1, ALPHA, z_meas, zero, 0, L.W_LOG)
+        got[mode] = ctx.get_particles(False, False, True)[2]
+        ctx.close()
+    assert np.isfinite(got["0"]).mean() > 0.8
+    assert np.array_equal(got["0"], got["1"], equal_nan=True) and np.array_equal(got["0"], got["auto"], equal_nan=True)
