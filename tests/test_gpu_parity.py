@@ -667,3 +667,63 @@ def test_one_kernel_and_two_launch_sector_query_agree_bit_for_bit(monkeypatch):
         ctx.close()
     assert np.isfinite(got["0"]).mean() > 0.8
     assert np.array_equal(got["0"], got["1"], equal_nan=True) and np.array_equal(got["0"], got["auto"], equal_nan=True)
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_float32_sector_query_on_random_beam_sets(seed):
+    """Random beam sets through the float32 throughput path -- few or many beams (up to 700: past the interval-only
+    kernel's fixed layouts), evenly spaced or scattered, with repeated angles, narrow or wide sectors (many intervals per
+    sector, or too many for the tables), headings from -14 to 14 rad, odd particle counts: the log-weights against the
+    beam model applied to the staged query's ranges of the same poses (mc_localization.py:116-171, :235-240)."""
+    from slam_amd import workload as W
+    L = _lib()
+    rng = np.random.RandomState(100 + seed)
+    grid = W.synthetic_map(256)
+    kind = seed % 5
+    if kind == 0:                                   # evenly spaced, any count
+        B = int(rng.choice([1, 2, 7, 90, 200, 400, 700]))
+        angles = [k * 360.0 / B for k in range(B)]
+    elif kind == 1:                                 # scattered
+        B = int(rng.randint(1, 60))
+        angles = list(rng.uniform(0.0, 360.0, B))
+    elif kind == 2:                                 # scattered with repeats and near-coincident angles
+        B = int(rng.randint(2, 40))
+        a = rng.uniform(0.0, 360.0, B)
+        a[1::3] = a[0::3][:len(a[1::3])]
+        a[2::5] = np.minimum(a[0::5][:len(a[2::5])] + 1e-7, 359.9999)
+        angles = list(a)
+    elif kind == 3:                                 # an arc only, unsorted
+        B = int(rng.randint(3, 120))
+        angles = list(rng.permutation(np.linspace(10.0, 10.0 + rng.uniform(20, 300), B)))
+    else:                                           # evenly spaced, offset from zero
+        B = int(rng.choice([13, 45, 180, 360]))
+        angles = [(k + 0.37) * 360.0 / B for k in range(B)]
+    half = float(rng.choice([0.5, 2.0, 5.0, 5.0, 12.0, 40.0])) * np.pi / 180.0
+    M = int(rng.choice([1, 63, 65, 1000, 4097]))
+    X = W.uniform_particles(grid, max(M, 8), seed=seed)[:M]
+    X[:, 2] = rng.uniform(-14.0, 14.0, M)
+    X = X.astype(np.float32).astype(np.float64)
+    ctx = L.Context(0, L.F32)
+    ctx.set_map(grid, W.RES, W.RES)
+    w4 = np.array([0.97, 0.005, 0.020, 0.005]); w4 /= w4.sum()
+    try:
+        ctx.set_sensor(angles, W.Z_MAX, 0.15, 1.0, w4, half)
+    except L.MclHipError as e:
+        ctx.close()
+        if "within one sector width of the 0/2pi seam" in str(e):      # a documented limit (64 such beams), refused loudly
+            pytest.skip("beam table beyond the documented limit: %s" % e)
+        raise
+    z_meas = ctx.raycast(np.array([3.0, 4.5, 0.3]), want_hits=False)[0][0]
+    ctx.set_particles(X)
+    ctx.shard_sample(0.0, 1e-12, 0.1, ALPHA, z_meas, np.zeros((M, 3, 12), np.int16), 0, L.W_LOG)
+    Xd, _, logw = ctx.get_particles(True, False, True)
+    R, _ = ctx.raycast(Xd, want_hits=False)
+    _, lwo, P = O.weights_from_ranges(R, z_meas, O.free_cell(Xd[:, 0], Xd[:, 1], grid), O.SensorParams())
+    fin = np.isfinite(lwo)
+    assert np.array_equal(np.isfinite(logw), fin)
+    if fin.any():
+        diff = np.abs(logw[fin] - lwo[fin])
+        size = np.sum(np.abs(np.log(P[fin])), axis=1)
+        # 1e-5 of the log-weight, or (where terms of either sign cancel) 1e-6 of what was summed
+        assert np.all((diff <= 1e-5 * np.maximum(1.0, np.abs(lwo[fin]))) | (diff <= 1e-6 * size)), (kind, B, half, M, diff.max())
+    ctx.close()
