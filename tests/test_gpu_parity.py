@@ -671,6 +671,17 @@ def test_one_kernel_and_two_launch_sector_query_agree_bit_for_bit(monkeypatch):
 
 @pytest.mark.parametrize("seed", range(48))
 def test_float32_sector_query_on_random_beam_sets(seed):
+    _random_beam_set_case(seed, False)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_float64_sector_query_on_random_beam_sets(seed):
+    """The same beam sets through the float64 instantiation with the raw product (one kernel holds the interval path,
+    the parked edge cells and the entry-by-entry redo): weights and log-weights to 1e-11."""
+    _random_beam_set_case(seed, True)
+
+
+def _random_beam_set_case(seed, f64):
     """Random beam sets through the float32 throughput path -- few or many beams (up to 700: past the interval-only
     kernel's fixed layouts), evenly spaced or scattered, with repeated angles, narrow or wide sectors (many intervals per
     sector, or too many for the tables), headings from -14 to 14 rad, odd particle counts: the log-weights against the
@@ -703,7 +714,7 @@ def test_float32_sector_query_on_random_beam_sets(seed):
     X = W.uniform_particles(grid, max(M, 8), seed=seed)[:M]
     X[:, 2] = rng.uniform(-14.0, 14.0, M)
     X = X.astype(np.float32).astype(np.float64)
-    ctx = L.Context(0, L.F32)
+    ctx = L.Context(0, L.F64 if f64 else L.F32)
     ctx.set_map(grid, W.RES, W.RES)
     w4 = np.array([0.97, 0.005, 0.020, 0.005]); w4 /= w4.sum()
     try:
@@ -715,12 +726,18 @@ def test_float32_sector_query_on_random_beam_sets(seed):
         raise
     z_meas = ctx.raycast(np.array([3.0, 4.5, 0.3]), want_hits=False)[0][0]
     ctx.set_particles(X)
-    ctx.shard_sample(0.0, 1e-12, 0.1, ALPHA, z_meas, np.zeros((M, 3, 12), np.int16), 0, L.W_LOG)
-    Xd, _, logw = ctx.get_particles(True, False, True)
+    ctx.shard_sample(0.0, 1e-12, 0.1, ALPHA, z_meas, np.zeros((M, 3, 12), np.int16), 0, L.W_PRODUCT if f64 else L.W_LOG)
+    Xd, wd, logw = ctx.get_particles(True, f64, True)
     R, _ = ctx.raycast(Xd, want_hits=False)
-    _, lwo, P = O.weights_from_ranges(R, z_meas, O.free_cell(Xd[:, 0], Xd[:, 1], grid), O.SensorParams())
+    wo, lwo, P = O.weights_from_ranges(R, z_meas, O.free_cell(Xd[:, 0], Xd[:, 1], grid), O.SensorParams())
     fin = np.isfinite(lwo)
     assert np.array_equal(np.isfinite(logw), fin)
+    if f64:
+        assert np.allclose(wd, wo, rtol=1e-11, atol=0.0)
+        size = np.sum(np.abs(np.log(P[fin])), axis=1) if fin.any() else np.zeros(0)
+        assert np.all(np.abs(logw[fin] - lwo[fin]) <= 1e-12 * np.maximum(1.0, size))
+        ctx.close()
+        return
     if fin.any():
         diff = np.abs(logw[fin] - lwo[fin])
         size = np.sum(np.abs(np.log(P[fin])), axis=1)
