@@ -81,7 +81,7 @@ RayParams make_ray_params(const mclhip_ctx* c) {
   P.ts_min = c->ts_min; P.ts_max = c->ts_max; P.inv_bw = c->inv_bw;
   P.relx = c->relx; P.G = c->G; P.ext_min = c->ext_min;
   P.iv_NE = c->iv_NE; P.iv_NB = c->iv_NB; P.iv_cmax = c->iv_cmax; P.iv_cmin = c->iv_cmin; P.iv_edge = c->iv_edge; P.iv_beam = c->iv_beam; P.iv_lut = c->iv_lut; P.iv_ends = c->iv_ends;
-  P.iv_origin = c->iv_origin; P.iv_th_hi = c->iv_th_hi;
+  P.iv_origin = c->iv_origin; P.iv_th_hi = c->iv_th_hi; P.iv_th_mid = c->iv_th_mid;
   P.half = c->half;
   P.two_pi_lo = M_PI * 2 - c->half;  // mc_localization.py:149
   P.two_pi_hi = M_PI * 2 + c->half;
@@ -579,8 +579,12 @@ int mcl::set_sensor_table(mclhip_ctx* c, const double* tab_rad, int B, double z_
           if (std::fabs(edge[m] - two_pi * m / NE) > 1e-9) c->iv_uniform = false;
         // headings for which no sector leaves the range the reference recognises: the highest beam angle + heading +
         // half-angle stays below two turns, the lowest beam angle + heading - half-angle above minus one turn
-        // (kept as one symmetric bound: the kernel holds one constant for it)
-        c->iv_th_hi = std::min(2.0 * two_pi - half - c->ts_max, two_pi - half + c->ts_min) - 1e-3;
+        // (kept as centre and half-width: one subtraction and one comparison in the kernel)
+        {
+          const double hi = 2.0 * two_pi - half - c->ts_max - 1e-3, lo = -two_pi + half - c->ts_min + 1e-3;
+          c->iv_th_mid = 0.5 * (hi + lo);
+          c->iv_th_hi = 0.5 * (hi - lo) - 1e-6;      // |heading - mid| <= this
+        }
       }
     }
   }

@@ -65,11 +65,11 @@ struct RayParams {
                                // sector holds the edge in its interior.  A bearing within rounding of the edge is decided for
                                // exactly these beams with the reference's float64 predicate.
   double iv_origin;            // angle of edge 0 (the lowest sector edge)
-  double iv_th_hi;             // headings in [-iv_th_hi, iv_th_hi] take this path: there the reference's predicate (one turn
-                               // of slack either way, mc_localization.py:148-149) is the circular one -- every beam angle +
-                               // heading stays within (-2 pi + half-angle, 4 pi - half-angle), and a bearing in [0, 2 pi) is
-                               // then never two turns away from it.  For beams over [0, 358] degrees with 5-degree sectors:
-                               // headings up to 355 degrees either way.
+  double iv_th_mid, iv_th_hi;  // headings with |heading - iv_th_mid| <= iv_th_hi take this path: there the reference's predicate
+                               // (one turn of slack either way, mc_localization.py:148-149) is the circular one -- every beam
+                               // angle + heading stays within (-2 pi + half-angle, 4 pi - half-angle), and a bearing in
+                               // [0, 2 pi) is then never two turns away from it.  For beams over [0, 358] degrees with
+                               // 5-degree sectors: headings from -355 to 357 degrees.
   // Two launches of the float32-mixture path: the interval-only kernel files the particles it does not serve ...
   int32_t* redo_list;          // 64 lists of sub_cap places each (blocks b, b + 64, ... append to list b % 64)
   uint32_t* redo_count;        // [64], zero before the launch
@@ -149,7 +149,7 @@ struct mclhip_ctx {
   uint16_t* inv_perm = nullptr;
   uint16_t* lut = nullptr;
   float* iv_edge = nullptr; uint16_t* iv_beam = nullptr; uint16_t* iv_lut = nullptr; uint32_t* iv_ends = nullptr;   // sector intervals (see RayParams)
-  int iv_NE = 0, iv_NB = 0, iv_cmax = 0, iv_cmin = 0; double iv_origin = 0.0, iv_th_hi = 0.0; bool iv_uniform = false;   // (uniform: the intervals are equally wide)
+  int iv_NE = 0, iv_NB = 0, iv_cmax = 0, iv_cmin = 0; double iv_origin = 0.0, iv_th_hi = 0.0, iv_th_mid = 0.0; bool iv_uniform = false;   // (uniform: the intervals are equally wide)
   float* relx = nullptr;
   int G = 0;
   double ext_min = 0;

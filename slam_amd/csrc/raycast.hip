@@ -336,7 +336,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
   };
   if (IVONLY && lane0 == 0) filed_cnt[0] = 0u;
   unsigned long long* const imin = rmin;                               // the same array read as minima per sector interval
-  const float iv_originf = (float)P.iv_origin, iv_inv_bwf = (float)((double)P.iv_NB / kTwoPi), iv_th_hif = (float)P.iv_th_hi;
+  const float iv_originf = (float)P.iv_origin, iv_inv_bwf = (float)((double)P.iv_NB / kTwoPi), iv_th_hif = (float)P.iv_th_hi, iv_th_midf = (float)P.iv_th_mid;
   const float iv_nearf = (float)kEdgeEps + (UNIF ? 4e-6f : 3e-6f);     // closer than this to a sector edge, float32 does not decide
   const float iv_wf = (float)(kTwoPi / (double)(P.iv_NE > 0 ? P.iv_NE : 1)), iv_inv_wf = (float)((double)P.iv_NE / kTwoPi);   // UNIF: interval width
 
@@ -393,7 +393,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
     const bool on_free = npm != 0;
     // headings for which the reference's predicate is the circular one take the interval path (wave-uniform); a
     // particle is done again entry by entry when a cell on a sector edge cannot be filed under intervals (see below)
-    const bool use_iv = IVK && IVN > 0 && !entry_by_entry && (float)th >= -iv_th_hif && (float)th <= iv_th_hif;
+    const bool use_iv = IVK && IVN > 0 && !entry_by_entry && fabsf((float)th - iv_th_midf) <= iv_th_hif;
     entry_by_entry = false;
     bool lane_redo = false;
     bool lane_parked = false;   // this lane has parked a cell

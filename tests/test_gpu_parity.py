@@ -286,8 +286,8 @@ def test_sector_intervals_against_the_oracle(beams):
     X = W.uniform_particles(grid, M, seed=3)
     th = rng.uniform(0.0, 2 * np.pi, M)
     arad = np.asarray(angles, float) * np.pi / 180.0
-    lim_hi = min(4 * np.pi - half - arad.max(), 2 * np.pi - half + arad.min()) - 1e-3   # the interval path serves
-    lim_lo = -lim_hi                                                                      # headings in [-lim_hi, lim_hi]
+    lim_hi = 4 * np.pi - half - arad.max() - 1e-3             # the interval path serves headings in [lim_lo, lim_hi]
+    lim_lo = -2 * np.pi + half - arad.min() + 1e-3
     th[:80] = lim_hi + rng.uniform(-2e-3, 2e-3, 80)           # around the upper limit of the interval path
     th[80:160] = lim_lo + rng.uniform(-2e-3, 2e-3, 80)        # around the lower limit
     th[160:200] = 2 * np.pi - 2 * half + rng.uniform(-2e-3, 2e-3, 40)   # where the highest sector starts to pass two turns
