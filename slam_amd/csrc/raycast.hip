@@ -208,10 +208,11 @@ __device__ __attribute__((noinline)) double slow_log(double v) { return log(v); 
 // CAP (with IVONLY): the LDS arrays are laid out for CAP beams, CAP intervals, sectors of at most kCapSpan intervals
 // and a look-up of cap_buckets(CAP) entries, whatever the table at hand needs: every address is then a compile-time
 // offset from the block's or the wave's base instead of a value kept in a scalar register.
-// UNIF (with IVONLY): the intervals are equally wide (evenly spaced beams): a bearing's interval and its edges are
-// arithmetic, not two dependent LDS reads.
+// UNIF (with IVONLY), non-zero: the intervals are equally wide (evenly spaced beams): a bearing's interval and its edges
+// are arithmetic, not two dependent LDS reads; positive: every sector spans exactly UNIF intervals (the loop over them
+// has a compile-time length: 2 % of the kernel).
 template <typename T, bool STAGE, bool PRODUCT, bool GRID = false, int WPB = kWavesPerBlock, bool RNOISE = false,
-          bool FAST = false, bool IVONLY = false, bool LISTED = false, int CAP = 0, bool UNIF = false>
+          bool FAST = false, bool IVONLY = false, bool LISTED = false, int CAP = 0, int UNIF = 0>
 // (waves per SIMD as a closed range: with only a lower bound the compiler budgets scalar registers for the ten waves
 // a small vector-register count would allow -- 80 instead of 96 -- and spills the rest into vector lanes)
 #define MCL_RAY_OCC(T, GRID, WPB, FAST, IVONLY) (GRID ? WPB / 4 : (IVONLY ? MCL_IVONLY_WAVES : (FAST ? MCL_FAST_WAVES : (sizeof(T) == 4 ? MCL_RAY_WAVES : 4))))
@@ -337,7 +338,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
   if (IVONLY && lane0 == 0) filed_cnt[0] = 0u;
   unsigned long long* const imin = rmin;                               // the same array read as minima per sector interval
   const float iv_originf = (float)P.iv_origin, iv_inv_bwf = (float)((double)P.iv_NB / kTwoPi), iv_th_hif = (float)P.iv_th_hi, iv_th_midf = (float)P.iv_th_mid;
-  const float iv_nearf = (float)kEdgeEps + (UNIF ? 4e-6f : 3e-6f);     // closer than this to a sector edge, float32 does not decide
+  const float iv_nearf = (float)kEdgeEps + (UNIF != 0 ? 4e-6f : 3e-6f);     // closer than this to a sector edge, float32 does not decide
   const float iv_wf = (float)(kTwoPi / (double)(P.iv_NE > 0 ? P.iv_NE : 1)), iv_inv_wf = (float)((double)P.iv_NE / kTwoPi);   // UNIF: interval width
 
   const unsigned long long r2max_bits = (unsigned long long)__double_as_longlong(P.r2max);
@@ -436,7 +437,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
           a = fmaf(-6.2831853071795865f, floorf(a * 0.15915494309189535f), a);   // [0, 2 pi) up to rounding; the ends are edges
           int m;
           float e0, e1;
-          if constexpr (UNIF) {
+          if constexpr (UNIF != 0) {
             // (the products differ from the table's float32 edges by an ulp at most: the band below allows for it, and a
             // bearing that lands one interval off is within the band of the edge between the two, which is what counts)
             m = (int)(a * iv_inv_wf);
@@ -727,9 +728,10 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
           // five intervals at a time, their reads in flight together (a read-minimum chain per interval: 0.845 -> 0.826 ms
           // at 180 beams, 1.43 -> 1.29 ms at 360; a branch of its own for exactly five measured 0.807 alone and 0.877
           // beside this loop -- the register allocation of this kernel turns on such things), the rest one by one; `uniform`: every sector spans as many intervals (evenly spaced beams)
-          const bool uniform = P.iv_cmin == P.iv_cmax;
+          const bool uniform = UNIF > 0 || P.iv_cmin == P.iv_cmax;
+          const int cmax_ = UNIF > 0 ? UNIF : P.iv_cmax;
           int j = 0;
-          for (; j + 5 <= P.iv_cmax; j += 5) {
+          for (; j + 5 <= cmax_; j += 5) {
             double v0 = __longlong_as_double((long long)run[j]), v1 = __longlong_as_double((long long)run[j + 1]),
                    v2 = __longlong_as_double((long long)run[j + 2]), v3 = __longlong_as_double((long long)run[j + 3]),
                    v4 = __longlong_as_double((long long)run[j + 4]);
@@ -739,7 +741,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
             }
             best = lower(best, lower(lower(lower(v0, v1), lower(v2, v3)), v4));
           }
-          for (; j < P.iv_cmax; ++j) {
+          for (; j < cmax_; ++j) {
             const double v = __longlong_as_double((long long)run[j]);
             best = lower(best, (uniform || j < cnt) ? v : best);
           }
@@ -1093,7 +1095,7 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
 #define MCL_RAY(TT, SS, PP) MCL_RAY_N(TT, SS, PP, false)
 #define MCL_RAY_N(TT, SS, PP, NN) MCL_RAY_F(TT, SS, PP, NN, false)
 #define MCL_RAY_F(TT, SS, PP, NN, FF) MCL_RAY_W(TT, SS, PP, NN, FF, kWavesPerBlock, false, false, 0)
-#define MCL_RAY_W(TT, SS, PP, NN, FF, WW, II, LL, CC) MCL_RAY_U(TT, SS, PP, NN, FF, WW, II, LL, CC, false)
+#define MCL_RAY_W(TT, SS, PP, NN, FF, WW, II, LL, CC) MCL_RAY_U(TT, SS, PP, NN, FF, WW, II, LL, CC, 0)
 #define MCL_RAY_U(TT, SS, PP, NN, FF, WW, II, LL, CC, UU)                                                              \
   do {                                                                                                               \
     auto kern = raycast_kernel<TT, SS, PP, false, WW, NN, FF, II, LL, CC, UU>;                                         \
@@ -1123,8 +1125,11 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
       // particles those blocks serve
       P.sub_cap = ((n + wpb - 1) / wpb + kSubLists - 1) / kSubLists * wpb;
       if ((int64_t)P.sub_cap * kSubLists > c->redo_cap + mclhip_ctx::kRedoSlack) return fail(c, MCLHIP_E_LIMIT, "left-over list too small");
-      if (cap == 192 && c->iv_uniform) MCL_RAY_U(float, false, false, false, true, kWavesPerBlock, true, false, 192, true);
-      else if (cap == 384 && c->iv_uniform) MCL_RAY_U(float, false, false, false, true, 2 * kWavesPerBlock, true, false, 384, true);
+      const bool even = c->iv_uniform, same = c->iv_cmin == c->iv_cmax;     // equally wide intervals; as many per sector
+      if (cap == 192 && even && same && c->iv_cmax == 5) MCL_RAY_U(float, false, false, false, true, kWavesPerBlock, true, false, 192, 5);
+      else if (cap == 192 && even) MCL_RAY_U(float, false, false, false, true, kWavesPerBlock, true, false, 192, -1);
+      else if (cap == 384 && even && same && c->iv_cmax == 10) MCL_RAY_U(float, false, false, false, true, 2 * kWavesPerBlock, true, false, 384, 10);
+      else if (cap == 384 && even) MCL_RAY_U(float, false, false, false, true, 2 * kWavesPerBlock, true, false, 384, -1);
       else if (cap == 192) MCL_RAY_W(float, false, false, false, true, kWavesPerBlock, true, false, 192);
       else if (cap == 384) MCL_RAY_W(float, false, false, false, true, 2 * kWavesPerBlock, true, false, 384);
       else if (wpb != kWavesPerBlock) MCL_RAY_W(float, false, false, false, true, 2 * kWavesPerBlock, true, false, 0);

@@ -11,7 +11,7 @@ if [ -d $src/mcl ]; then
   cp $src/mcl_bench_under_profiler.json profiles/${tag}_bench_under_profiler.json
   python tools/pmc_summary.py $src/mcl profiles/${tag}_pmc_per_kernel.json > /dev/null
   python tools/valu_roofline.py profiles/${tag}_pmc_per_kernel.json profiles/r02_valu_issue_cost.json /tmp/raycast_$tag.s \
-      raycast_kernelIfLb0ELb0ELb0ELi4ELb0ELb1ELb1ELb0ELi192ELb1E profiles/${tag}_valu_roofline.json "raycast_kernel<float, false, false, false, 4, false, true, true, false, 192, true>"
+      raycast_kernelIfLb0ELb0ELb0ELi4ELb0ELb1ELb1ELb0ELi192ELi5E profiles/${tag}_valu_roofline.json "raycast_kernel<float, false, false, false, 4, false, true, true, false, 192, 5>"
 fi
 if [ -d $src/grid ]; then
   cp $src/grid_trace/t_kernel_stats.csv profiles/${tag}_grid_kernel_stats.csv
