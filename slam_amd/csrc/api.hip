@@ -465,7 +465,6 @@ int mcl::set_sensor_table(mclhip_ctx* c, const double* tab_rad, int B, double z_
     for (int k = 0; k < B; ++k)
       if (ts[k] - c->ts_min >= two_pi - 2.0 * reach - 1e-6) ++G;
   if (G > B - 1) G = B > 1 ? B - 1 : 0;   // never an image of every beam
-  if (G > 64) return fail(c, MCLHIP_E_LIMIT, "more than 64 beams within one sector width of the 0/2pi seam");
   for (int k = B - G; k < B; ++k) relx.push_back((float)((ts[k] - c->ts_min) - two_pi));
   for (int k = 0; k < B; ++k) relx.push_back((float)(ts[k] - c->ts_min));
   c->G = G;

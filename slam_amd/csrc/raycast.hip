@@ -635,16 +635,19 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       // a beam that also has a seam image keeps the smaller of the two minima in both entries
       // (entry G + k is beam k; entry g < G is the image of beam B - G + g)
-      if (!use_iv && lane < G) {
-        const int real = B + lane;   // == G + (B - G + lane)
-        if (!STAGE || phase == 0) {
-          const unsigned long long a = rmin[lane], b = rmin[real];
-          const unsigned long long m = a < b ? a : b;
-          rmin[lane] = m;
-          rmin[real] = m;
-        } else {
-          const unsigned long long a = aux[lane], b = aux[real];
-          aux[real] = a < b ? a : b;
+      if (!use_iv) {
+#pragma unroll 1
+        for (int g = lane; g < G; g += 64) {
+          const int real = B + g;   // == G + (B - G + g)
+          if (!STAGE || phase == 0) {
+            const unsigned long long a = rmin[g], b = rmin[real];
+            const unsigned long long m = a < b ? a : b;
+            rmin[g] = m;
+            rmin[real] = m;
+          } else {
+            const unsigned long long a = aux[g], b = aux[real];
+            aux[real] = a < b ? a : b;
+          }
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
