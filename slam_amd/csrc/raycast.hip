@@ -978,7 +978,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
   }
   if constexpr (IVONLY) flush_filed(lane0);
 #ifdef MCL_STAMPS
-  if (lane == 0)
+  if (lane0 == 0)
     for (int i = 0; i < 8; ++i) atomicAdd(&P.stamps[i], acc[i]);
 #endif
 #ifdef MCL_COUNTS
