@@ -424,7 +424,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
       const double ox = (double)((float)col * P.res_xf);  // mc_localization.py:68-71: float32 products
       const double oy = (double)((float)row * P.res_yf);
       const double dx = ox - x, dy = oy - y;              // :124-125, float64
-      const double r2 = dx * dx + dy * dy;                // :126
+      // :126.  The float32 likelihood takes the fused form (one rounding less than the reference's sum of two rounded
+      // products: a last-bit difference in float64, nine orders of magnitude below that path's tolerance)
+      const double r2 = FAST ? fma(dx, dx, dy * dy) : dx * dx + dy * dy;
       COUNT(1);
       bool hit = valid && r2 <= P.r2max;       // :127
       const float aaf = bearing_f32((float)dy, (float)dx);
@@ -669,7 +671,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
             const int E = (int)(q >> 32);
             const int col = (int)(e & 0xffffu), row = (int)(e >> 16);
             const double dx = (double)((float)col * P.res_xf) - x, dy = (double)((float)row * P.res_yf) - y;   // as in match_cell
-            const unsigned long long r2bits = (unsigned long long)__double_as_longlong(dx * dx + dy * dy);
+            const unsigned long long r2bits = (unsigned long long)__double_as_longlong(FAST ? fma(dx, dx, dy * dy) : dx * dx + dy * dy);
             const int left = E == 0 ? IVN - 1 : E - 1, right = E;
             const unsigned int ends = s_ivends[E];
             const double a_exact = exact_bearing(dy, dx);            // :133-135
