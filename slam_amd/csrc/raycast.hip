@@ -111,13 +111,14 @@ __device__ inline float wave_sum_f32(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-// Bearing of (dx, dy) in [0, 2pi), float32, |error| < 1e-6 rad for finite inputs (0 for dx = dy = 0,
-// as atan2 gives).  Only used to pick candidate beams: decisions within 1e-5 rad of a sector edge
+// Bearing of (dx, dy) in [0, 2pi) (SIGNED: in (-pi, pi], one reflection less), float32, |error| < 1e-6 rad for finite
+// inputs (0 for dx = dy = 0, as atan2 gives).  Only used to pick candidate beams: decisions within 1e-5 rad of a sector edge
 // are taken again with the float64 atan2.  Odd minimax polynomial of degree 15 for atan on [0, 1]
 // (1.4e-7), v_rcp_f32 for the ratio, three reflections.
+template <bool SIGNED = false>
 __device__ inline float bearing_f32(float dy, float dx) {
   const float ax = fabsf(dx), ay = fabsf(dy);
-  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  const float mx = fmaxf(fmaxf(ax, ay), 1.0e-30f), mn = fminf(ax, ay);   // (dx = dy = 0: the ratio is 0, and so is the result)
   const float t = mn * __builtin_amdgcn_rcpf(mx);
   const float s = t * t;
   float p = -0.004054124001413584f;
@@ -131,8 +132,9 @@ __device__ inline float bearing_f32(float dy, float dx) {
   float r = t * p;
   r = ay > ax ? 1.5707964f - r : r;
   r = dx < 0.0f ? 3.1415927f - r : r;
-  r = dy < 0.0f ? 6.2831855f - r : r;
-  return mx > 0.0f ? r : 0.0f;
+  if constexpr (SIGNED) r = copysignf(r, dy);     // (-pi, pi]: for callers that reduce the angle themselves
+  else r = dy < 0.0f ? 6.2831855f - r : r;
+  return r;
 }
 
 // float64 bearing in [0, 2pi) exactly as the reference forms it (mc_localization.py:133-135).
@@ -339,7 +341,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
   unsigned long long* const imin = rmin;                               // the same array read as minima per sector interval
   const float iv_originf = (float)P.iv_origin, iv_inv_bwf = (float)((double)P.iv_NB / kTwoPi), iv_th_hif = (float)P.iv_th_hi, iv_th_midf = (float)P.iv_th_mid;
   const float iv_nearf = (float)kEdgeEps + (UNIF != 0 ? 4e-6f : 3e-6f);     // closer than this to a sector edge, float32 does not decide
-  const float iv_wf = (float)(kTwoPi / (double)(P.iv_NE > 0 ? P.iv_NE : 1)), iv_inv_wf = (float)((double)P.iv_NE / kTwoPi);   // UNIF: interval width
+  const float iv_near_uf = 0.5f - iv_nearf * (float)((double)P.iv_NE / kTwoPi);   // UNIF: the same band in interval widths, from the middle
+  const float iv_inv_wf = (float)((double)P.iv_NE / kTwoPi);   // UNIF: intervals per radian
 
   const unsigned long long r2max_bits = (unsigned long long)__double_as_longlong(P.r2max);
   const float disk_r = (float)(P.z_max * (1.0 + 1e-5) + 0.02 * (P.res_x < P.res_y ? P.res_x : P.res_y));
@@ -429,7 +432,12 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
       const double r2 = FAST ? fma(dx, dx, dy * dy) : dx * dx + dy * dy;
       COUNT(1);
       bool hit = valid && r2 <= P.r2max;       // :127
-      const float aaf = bearing_f32((float)dy, (float)dx);
+#ifdef MCL_X_F32D
+      // (FAST: the pose is a float32 pair, so the float32 difference is the rounded float64 one)
+      const float aaf = FAST ? bearing_f32<IVONLY>((float)row * P.res_yf - yf, (float)col * P.res_xf - xf) : bearing_f32<IVONLY>((float)dy, (float)dx);
+#else
+      const float aaf = bearing_f32<IVONLY>((float)dy, (float)dx);   // (the interval path reduces the angle itself)
+#endif
       const unsigned long long r2bits = (unsigned long long)__double_as_longlong(r2);
       if constexpr (IVK) {
         if (use_iv) {
@@ -438,14 +446,15 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
           float a = (aaf - thf) - iv_originf;                         // in (-4 pi, 5 pi) for the headings of this path
           a = fmaf(-6.2831853071795865f, floorf(a * 0.15915494309189535f), a);   // [0, 2 pi) up to rounding; the ends are edges
           int m;
-          float e0, e1;
+          float e0 = 0.0f, e1 = 0.0f, uf = 0.0f;
           if constexpr (UNIF != 0) {
-            // (the products differ from the table's float32 edges by an ulp at most: the band below allows for it, and a
-            // bearing that lands one interval off is within the band of the edge between the two, which is what counts)
-            m = (int)(a * iv_inv_wf);
-            m = m < 0 ? 0 : (m > IVN - 1 ? IVN - 1 : m);
-            e0 = (float)m * iv_wf;
-            e1 = e0 + iv_wf;
+            // (a >= -1e-6 and the conversion truncates towards zero: only the upper end needs a clamp; NaN converts to 0.
+            // The product is within 4e-7 rad of the true place: the band below allows for it, and a bearing that lands
+            // one interval off is within the band of the edge between the two, which is what counts)
+            const float au = a * iv_inv_wf;
+            m = (int)au;
+            m = m > IVN - 1 ? IVN - 1 : m;
+            uf = au - (float)m;        // place inside the interval, in interval widths
           } else {
             int bkt = (int)(a * iv_inv_bwf);
             bkt = bkt < 0 ? 0 : (bkt > P.iv_NB - 1 ? P.iv_NB - 1 : bkt);
@@ -456,8 +465,14 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
               while (e1 <= a && m + 1 < IVN) { ++m; e0 = e1; e1 = s_ivedge[m + 1]; }
             }
           }
-          const bool at_lower = !(a - e0 >= iv_nearf);                              // also NaN
-          const bool near_edge = at_lower || !(e1 - a >= iv_nearf);
+          bool at_lower, near_edge;
+          if constexpr (UNIF != 0) {
+            near_edge = !(fabsf(uf - 0.5f) <= iv_near_uf);                          // also NaN
+            at_lower = !(uf >= 0.5f);
+          } else {
+            at_lower = !(a - e0 >= iv_nearf);                                       // also NaN
+            near_edge = at_lower || !(e1 - a >= iv_nearf);
+          }
           if (hit && !near_edge) atomicMin(&imin[m], r2bits);
           if (hit && near_edge) {
             // within rounding of edge E: parked, decided in float64 after the walk (rare; keeps the call out of this loop)
@@ -744,7 +759,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
               v0 = j < cnt ? v0 : best; v1 = j + 1 < cnt ? v1 : best; v2 = j + 2 < cnt ? v2 : best;
               v3 = j + 3 < cnt ? v3 : best; v4 = j + 4 < cnt ? v4 : best;
             }
-            best = lower(best, lower(lower(lower(v0, v1), lower(v2, v3)), v4));
+            // (every minimum starts at z_max^2: the first group of a uniform run needs no cap of its own)
+            const double g5 = lower(lower(lower(v0, v1), lower(v2, v3)), v4);
+            best = (UNIF > 0 && j == 0) ? g5 : lower(best, g5);
           }
           for (; j < cmax_; ++j) {
             const double v = __longlong_as_double((long long)run[j]);
