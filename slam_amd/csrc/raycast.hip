@@ -432,12 +432,10 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
       const double r2 = FAST ? fma(dx, dx, dy * dy) : dx * dx + dy * dy;
       COUNT(1);
       bool hit = valid && r2 <= P.r2max;       // :127
-#ifdef MCL_X_F32D
-      // (FAST: the pose is a float32 pair, so the float32 difference is the rounded float64 one)
-      const float aaf = FAST ? bearing_f32<IVONLY>((float)row * P.res_yf - yf, (float)col * P.res_xf - xf) : bearing_f32<IVONLY>((float)dy, (float)dx);
-#else
-      const float aaf = bearing_f32<IVONLY>((float)dy, (float)dx);   // (the interval path reduces the angle itself)
-#endif
+      // (the interval path reduces the angle itself.  FAST: pose and cell coordinates are float32 numbers, so their
+      // float32 difference is the float64 one rounded -- the same operand without two conversions)
+      const float aaf = FAST ? bearing_f32<IVONLY>((float)row * P.res_yf - yf, (float)col * P.res_xf - xf)
+                             : bearing_f32<IVONLY>((float)dy, (float)dx);
       const unsigned long long r2bits = (unsigned long long)__double_as_longlong(r2);
       if constexpr (IVK) {
         if (use_iv) {
