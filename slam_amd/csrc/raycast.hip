@@ -591,10 +591,16 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
 
     STAMP(0);
     {
-      const int n_clear = use_iv ? IVN : RS;
-      for (int k = lane; k < n_clear; k += 64) {
-        rmin[k] = r2max_bits;
-        if (STAGE) aux[k] = 0xffffffffull;
+      if constexpr (STATIC_L) {
+        // the fixed layout's table holds CAP + kCapSpan entries: the whole of CAP is cleared, whatever part is in use
+#pragma unroll
+        for (int j = 0; j < CAP; j += 64) rmin[lane + j] = r2max_bits;
+      } else {
+        const int n_clear = use_iv ? IVN : RS;
+        for (int k = lane; k < n_clear; k += 64) {
+          rmin[k] = r2max_bits;
+          if (STAGE) aux[k] = 0xffffffffull;
+        }
       }
       if (IVK && lane == 0) edge_cnt[0] = 0u;
     }
