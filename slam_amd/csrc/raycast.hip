@@ -410,7 +410,23 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
     const int tcy = pose_ok ? ((int)floor(fyc)) >> (3 - kQueryShift) : 0;
     // the particle's slice of neighbourhood cells; NaN / infinite headings match no beam
     unsigned int first_cell = 0u, n_cells = 0u;
-    {
+    if constexpr (IVONLY) {
+      // the map fields straight from the argument block (the kernel's first argument), once per particle: one scalar
+      // load instead of six scalar registers held across the whole loop, which at eight waves per SIMD were spilled to
+      // vector lanes and read back for every particle (16 v_readlane: 0.71 -> 0.68 ms at 2^20 x 180; the same in the
+      // other instantiations measured no gain)
+      typedef const __attribute__((address_space(4))) RayParams* KP;
+      KP Pk = (KP)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(Pk));
+      const int ETW_ = Pk->ETW, ETH_ = Pk->ETH, rtx_ = Pk->rtx, rty_ = Pk->rty;
+      const uint32_t* nbr_off_ = Pk->nbr_off;
+      const int ex = tcx + rtx_, ey = tcy + rty_;
+      if (pose_ok && fabs(th) < INFINITY && ex >= 0 && ex < ETW_ && ey >= 0 && ey < ETH_ && (!IVONLY || use_iv)) {
+        const unsigned int* no = nbr_off_ + ((size_t)ey * ETW_ + ex);
+        first_cell = no[0];
+        n_cells = no[1] - first_cell;
+      }
+    } else {
       const int ex = tcx + rtx, ey = tcy + rty;
       if (pose_ok && fabs(th) < INFINITY && ex >= 0 && ex < ETW && ey >= 0 && ey < ETH && (!IVONLY || use_iv)) {
         const unsigned int* no = nbr_off + ((size_t)ey * ETW + ex);
