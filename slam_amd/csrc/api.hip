@@ -141,7 +141,7 @@ int build_ring_table(mclhip_ctx* c) {
   if (e != hipSuccess) return fail(c, MCLHIP_E_HIP, std::string("neighbourhood count: ") + hipGetErrorString(e));
   std::vector<uint32_t> off(ne + 1);
   uint64_t acc = 0;
-  for (size_t t = 0; t < ne; ++t) { off[t] = (uint32_t)acc; acc += cnt[t]; }
+  for (size_t t = 0; t < ne; ++t) { off[t] = (uint32_t)acc; acc += (cnt[t] + 63u) & ~63ull; }   // whole batches of 64: the fill pads them
   if (acc > 0xffffffffull) return fail(c, MCLHIP_E_LIMIT, "neighbourhood lists exceed 2^32 entries (map too large for this z_max)");
   off[ne] = (uint32_t)acc;
   if (c->nbr_off) { (void)hipFree(c->nbr_off); c->nbr_off = nullptr; }

@@ -48,7 +48,7 @@ int launch_build_tiles(mclhip_ctx* c, const uint8_t* d_map) {
 // Neighbourhood lists.  For every query tile of the grid (kQueryCells^2 cells; the grid extended by the ring
 // radius on each side) the obstacle cells that can be within reach of some point of the query tile, nearest
 // obstacle tile first: what a particle standing anywhere in that query tile has to look at is then one
-// contiguous slice.  The ring table names the 8x8 obstacle tiles around the 8x8 tile the query tile lies in; of
+// contiguous slice (a multiple of 64 entries long: see the padding at the end of nbr_list_kernel).  The ring table names the 8x8 obstacle tiles around the 8x8 tile the query tile lies in; of
 // those, the ones whose nearest cell is out of reach of the query tile are left out as a whole, and of the others
 // every cell is tested by itself (a list of whole tiles is half as long again: it covers a disc whose radius is
 // larger by a tile's diagonal).
@@ -113,6 +113,12 @@ __global__ __launch_bounds__(256) void nbr_list_kernel(const uint32_t* __restric
     out += (uint32_t)__popcll(km);
   }
   if (!FILL && lane == 0) out_buf[t] = out;
+  if (FILL) {
+    // A list occupies whole batches of 64 entries; the rest of the last batch is a cell no pose of the query tile can
+    // reach (the far end of the column range: reach is at most 127 tiles), so that a walk needs no per-lane bounds.
+    const uint32_t pad = qcol0 < 32768 ? 0xffffu : 0u;   // row 0, last or first column
+    for (uint32_t i = out + (uint32_t)lane; i < nbr_off[t + 1]; i += 64u) out_buf[i] = pad;
+  }
 }
 
 static NbrGeom nbr_geom(const mclhip_ctx* c) {

@@ -633,11 +633,13 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
         // The interval path matches the fetched batches as they come: a list holds about 200 cells for the 130 within
         // z_max, and without the entry-by-entry test a cell outside the disc costs less in a half-empty batch than the
         // compaction of every batch does (0.884 -> 0.856 ms at 2^20 x 180).
-        for (unsigned int sb = 0; sb < n_cells; sb += 64) {
+        // (a list is whole batches of 64, padded with a cell out of every pose's reach: no per-lane bounds)
+        const unsigned int n_list = (unsigned int)__builtin_amdgcn_readfirstlane((int)n_cells);
+        for (unsigned int sb = 0; sb < n_list; sb += 64) {
           const unsigned int e = e_next;
           COUNT(0);
-          if (sb + 64 + lane < n_cells) e_next = nbr_cells[first_cell + sb + 64 + lane];   // next batch in flight
-          match_cell(e, sb + lane < n_cells, phase);
+          if (sb + 64 < n_list) e_next = nbr_cells[first_cell + sb + 64 + lane];   // next batch in flight
+          match_cell(e, true, phase);
         }
         n_cells = 0u;
       }
