@@ -354,6 +354,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
   const double reach = P.half + 2.0 * kEdgeEps;   // candidate window half-width
   const double inv_two_pi = 1.0 / kTwoPi;
   const double inv_res_x = 1.0 / P.res_x, inv_res_y = 1.0 / P.res_y;
+  const float inv_res_xf = (float)inv_res_x, inv_res_yf = (float)inv_res_y;
   const float reachf = (float)reach, inv_bwf = (float)P.inv_bw, ext_minf = (float)P.ext_min;
   const float ts_minf = (float)P.ts_min, spanf = (float)span, inv_two_pif = (float)inv_two_pi;
   const int G = P.G, NX = P.G + B;
@@ -420,8 +421,13 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
       asm volatile("" : "+s"(Pk));
       const int ETW_ = Pk->ETW, ETH_ = Pk->ETH, rtx_ = Pk->rtx, rty_ = Pk->rty;
       const uint32_t* nbr_off_ = Pk->nbr_off;
-      const int ex = tcx + rtx_, ey = tcy + rty_;
-      if (pose_ok && fabs(th) < INFINITY && ex >= 0 && ex < ETW_ && ey >= 0 && ey < ETH_ && (!IVONLY || use_iv)) {
+      // (float32 state: the tile index from a float32 product -- off by one at an exact tile edge at worst, which the
+      // lists' cell of slack covers, like the float64 product's rounding)
+      const float fxcf = (float)nx * inv_res_xf, fycf = (float)ny * inv_res_yf;
+      const bool pose_ok_ = (fabsf(fxcf) < 1.0e6f) && (fabsf(fycf) < 1.0e6f) && fabsf((float)nth) < INFINITY;
+      const int ex = (pose_ok_ ? ((int)floorf(fxcf)) >> (3 - kQueryShift) : 0) + rtx_;
+      const int ey = (pose_ok_ ? ((int)floorf(fycf)) >> (3 - kQueryShift) : 0) + rty_;
+      if (pose_ok_ && ex >= 0 && ex < ETW_ && ey >= 0 && ey < ETH_ && use_iv) {
         const unsigned int* no = nbr_off_ + ((size_t)ey * ETW_ + ex);
         first_cell = no[0];
         n_cells = no[1] - first_cell;
