@@ -337,7 +337,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
   };
-  if (IVONLY && lane0 == 0) filed_cnt[0] = 0u;
+  if (IVONLY && lane0 == 0) { filed_cnt[0] = 0u; edge_cnt[0] = 0u; }
   unsigned long long* const imin = rmin;                               // the same array read as minima per sector interval
   const float iv_originf = (float)P.iv_origin, iv_inv_bwf = (float)((double)P.iv_NB / kTwoPi), iv_th_hif = (float)P.iv_th_hi, iv_th_midf = (float)P.iv_th_mid;
   const float iv_nearf = (float)kEdgeEps + (UNIF != 0 ? 4e-6f : 3e-6f);     // closer than this to a sector edge, float32 does not decide
@@ -624,7 +624,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
           if (STAGE) aux[k] = 0xffffffffull;
         }
       }
-      if (IVK && lane == 0) edge_cnt[0] = 0u;
+      if constexpr (!IVONLY) { if (IVK && lane == 0) edge_cnt[0] = 0u; }   // (IVONLY: cleared once, and again by whoever used it)
     }
     for (int phase = 0; phase < (STAGE ? 2 : 1); ++phase) {
       int q_head = 0, q_count = 0;   // wave-uniform state of the ring of cells waiting to be matched
@@ -707,6 +707,12 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
         // entry-by-entry test.
         // (most particles park nothing: a flag kept in a register spares them the read of the count and its wait)
         const int nq = __ballot(lane_parked) != 0ull ? __builtin_amdgcn_readfirstlane((int)edge_cnt[0]) : 0;
+        if constexpr (IVONLY) {
+          if (nq > 0) {   // most particles park nothing: the count is cleared by the ones that did
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (lane == 0) edge_cnt[0] = 0u;
+          }
+        }
         if (nq > 0) {
           if (lane < nq && lane < kEdgeQueue) {
             const unsigned long long q = edgeq[lane];
