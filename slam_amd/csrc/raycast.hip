@@ -223,6 +223,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
     RayParams P, const T* __restrict__ xs, const T* __restrict__ ys, const T* __restrict__ ths,
     const uint8_t* __restrict__ pm, int64_t n, double* __restrict__ w_out, double* __restrict__ logw_out,
     double* __restrict__ ranges_out, int32_t* __restrict__ hits_out) {
+  // (P must stay the first argument and the list up to logw_out as it is: the interval-only instantiation reads both
+  // through the argument block's address, see Pk and KArgs below)
   extern __shared__ __align__(16) unsigned char smem[];
   // LISTED: the launch is sized for every particle, the list is usually short: a block beyond it leaves at once
   if constexpr (LISTED) {
@@ -931,7 +933,16 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
       if (nfac) l2s += log2_of_product(prod);
       // (64 lane totals of a few tens each: a float32 sum is good to 3e-7 of the result)
       const double lsd = (double)wave_sum_f32((float)l2s) * 0.6931471805599453;
-      if (lane == 0) logw_out[p] = on_free ? lsd : -INFINITY;
+      if constexpr (IVONLY) {
+        // (the output pointer from the argument block, like the map fields above, instead of a scalar pair spilled
+        // across the loop: -1.5 % of the launch.  KArgs repeats the head of this kernel's argument list, in order.)
+        struct KArgs { RayParams P; const void* xs; const void* ys; const void* ths; const void* pm; int64_t n; double* w_out; double* logw_out; };
+        typedef const __attribute__((address_space(4))) KArgs* KA;
+        KA ka = (KA)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        double* const lo = ka->logw_out;
+        if (lane == 0) lo[p] = on_free ? lsd : -INFINITY;
+      } else if (lane == 0) logw_out[p] = on_free ? lsd : -INFINITY;
     } else {
       typedef T R;  // likelihood arithmetic follows the state dtype
       // log-weight: each lane multiplies its few p_k in float64 and takes one logarithm of the
