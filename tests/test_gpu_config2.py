@@ -1,5 +1,5 @@
 """The per-GPU share of the largest configuration -- a 16384^2 synthetic grid, 360 beams, 2^23 particles in float32
-state -- on one GPU: the map structures at that size (1.2e9 neighbourhood entries behind 32-bit offsets) against
+state -- on one GPU: the map structures at that size (1.0e9 neighbourhood entries behind 32-bit offsets) against
 the oracle on a subset, the whole update through its size-independent properties, the cost of set_map, and the
 refusal just past the 2^32-entry limit."""
 import time
