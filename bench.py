@@ -58,6 +58,31 @@ def parse():
     return ap.parse_args()
 
 
+def visible_gpus(topology="/sys/class/kfd/kfd/topology/nodes"):
+    """GPUs this process would see, counted WITHOUT loading torch or the HIP runtime (the launcher forks the ranks and
+    must not have initialised a GPU itself): the kernel driver's topology nodes that have SIMDs, narrowed by
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when set.  None when the topology cannot be read
+    (the ranks then report a missing device themselves)."""
+    import glob
+    nodes = 0
+    files = glob.glob(os.path.join(topology, "*", "properties"))
+    if not files:
+        return None
+    for f in files:
+        try:
+            for line in open(f):
+                k, _, v = line.partition(" ")
+                if k == "simd_count" and int(v) > 0:
+                    nodes += 1
+        except (OSError, ValueError):
+            return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            nodes = min(nodes, len([x for x in v.split(",") if x.strip() != ""]))
+    return nodes
+
+
 def launch_ranks(a):
     """`python bench.py --gpus N` without a launcher around it: start N fresh rank processes (RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* in their environment) and wait for them.  The parent touches no GPU.  Rank 0 writes the
@@ -66,9 +91,8 @@ def launch_ranks(a):
     import subprocess
     n = a.gpus
     if not (a.dry_run or a.share_gpu):
-        import torch
-        have = torch.cuda.device_count()          # counts devices without initialising the GPU runtime
-        if have < n:
+        have = visible_gpus()
+        if have is not None and have < n:
             sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible\n" % (n, have))
             return 2
     with socket.socket() as sk:
@@ -125,7 +149,8 @@ def cpu_baseline(grid, angles, X, z_meas, ut, n_particles):
     orc.w = np.exp(lw)
     orc.resample(rng.rand() / n_particles, clamp=True)
     dt = time.perf_counter() - t0
-    return {"value": n_particles * len(angles) / dt, "unit": "particle-beam evals/s", "cores": 1, "kind": "port",
+    return {"value": n_particles * len(angles) / dt, "unit": "particle-beam evals/s", "cores": 1, "host_cores": os.cpu_count(),
+            "host_cores_usable": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None, "kind": "port",
             "sample": "%d particles x %d beams, full obstacle list (%d cells), one update in %.1f s; "
                       "cost is linear in the particle count" % (n_particles, len(angles), len(orc.lut), dt)}
 

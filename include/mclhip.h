@@ -115,15 +115,19 @@ int64_t mclhip_num_particles(mclhip_ctx* ctx);
 int mclhip_raycast(mclhip_ctx* ctx, const double* poses_aos, int64_t n, double* ranges, int32_t* hit_cell);
 
 /* mclhip_raycast for callers that cannot allocate device memory (a serving loop
- * that measures one true pose per step, code under HIP graph capture around it,
- * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same
- * arguments and results as mclhip_raycast, but the staging the kernels need (poses,
- * ranges and hit cells on the device) lives in a 960-KiB array inside the library's
- * code object instead of being allocated and freed per call, so the call performs
- * no hipMalloc / hipFree.  Limits: n <= 4096 and n * B <= 65536, more is refused with
- * MCLHIP_E_LIMIT.  Map and sensor must both be set (the map tables are built by
- * mclhip_set_map / mclhip_set_sensor, whichever comes second).  Every context on one
- * GPU shares that GPU's array: calls that overlap on one GPU race. */
+ * that measures one true pose per step, harnesses that forbid hipMalloc).  No
+ * counterpart in the reference.  Same arguments and results as mclhip_raycast, but
+ * the staging the kernels need (poses, ranges and hit cells on the device) lives in
+ * a 960-KiB array inside the library's code object instead of being allocated and
+ * freed per call: the call performs no hipMalloc / hipFree.  It is synchronous
+ * (copies from and to the caller's host buffers, then waits for the stream), so it
+ * cannot itself be recorded into a HIP graph.  Limits: n <= 4096 and n * B <= 65536,
+ * more is refused with MCLHIP_E_LIMIT.  Map and sensor must both be set (the map
+ * tables are built by mclhip_set_map / mclhip_set_sensor, whichever comes second).
+ * Every context on one GPU shares that GPU's array; the library serialises the calls
+ * of one process on it (a mutex per device, held from the upload of the poses to the
+ * read-back of the results), so contexts driven from different threads do not mix
+ * their data -- they wait for each other.  Other processes have their own copy. */
 int mclhip_raycast_static(mclhip_ctx* ctx, const double* poses_aos, int64_t n, double* ranges, int32_t* hit_cell);
 
 /* Replaces MCLocalization.sample_motion_model_velocity (mc_localization.py:74-114)

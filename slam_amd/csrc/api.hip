@@ -42,9 +42,12 @@ static __device__ __align__(256) unsigned char scratch[kStaticBytes];
 // In host code `scratch` is only a handle of the symbol, not an address a kernel or a copy can use: the
 // address of each device's copy is looked up once per device (with that device current) and kept here.
 constexpr int kMaxDevices = 64;
-static std::mutex g_scratch_mutex;
+static std::mutex g_scratch_mutex;                    // guards the two tables below
 static unsigned char* g_scratch_ptr[kMaxDevices] = {};
 static hipError_t g_scratch_err[kMaxDevices] = {};
+// One caller at a time stages through a device's array: contexts on one GPU share it, and a second thread's poses
+// would otherwise land between the first one's upload and its read-back.  Held for the whole of a call.
+static std::mutex g_scratch_call_mutex[kMaxDevices];
 
 // called from mclhip_create with the context's device current
 static void resolve_static_scratch(int device) {
@@ -713,11 +716,17 @@ int mclhip_raycast_static(mclhip_ctx* c, const double* poses, int64_t n, double*
   if (n > kStaticMaxPoses || n * (int64_t)B > kStaticMaxEntries)
     return fail(c, MCLHIP_E_LIMIT, "mclhip_raycast_static takes at most 4096 poses and 65536 (pose, beam) pairs per call; "
                                    "use mclhip_raycast for more");
-  unsigned char* const base = (c->device >= 0 && c->device < kMaxDevices) ? g_scratch_ptr[c->device] : nullptr;
+  if (c->device < 0 || c->device >= kMaxDevices) return fail(c, MCLHIP_E_LIMIT, "device index beyond the static array's table");
+  unsigned char* base = nullptr;
+  hipError_t base_err = hipSuccess;
+  {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    base = g_scratch_ptr[c->device];
+    base_err = g_scratch_err[c->device];
+  }
   if (!base)
-    return fail(c, MCLHIP_E_HIP, std::string("address of the static device array is not known: ") +
-                                     hipGetErrorString(c->device >= 0 && c->device < kMaxDevices ? g_scratch_err[c->device]
-                                                                                                : hipErrorInvalidDevice));
+    return fail(c, MCLHIP_E_HIP, std::string("address of the static device array is not known: ") + hipGetErrorString(base_err));
+  std::lock_guard<std::mutex> call_lock(g_scratch_call_mutex[c->device]);   // until the results are back on the host
   double* const d_aos = reinterpret_cast<double*>(base + kStaticOffAos);
   double* const dx = reinterpret_cast<double*>(base + kStaticOffX);
   double* const dy = reinterpret_cast<double*>(base + kStaticOffY);

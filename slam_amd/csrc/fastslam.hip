@@ -965,6 +965,8 @@ static int fs_enqueue_kernel(mclhip_ctx* c, double v, double omega, double dt, c
   if (!alpha || (L > 0 && (!truth_r || !truth_phi || !truth_valid)) || L < 0) return fail(c, MCLHIP_E_ARG, "alpha / truth arrays NULL");
   FsState* s = (FsState*)c->fs;
   const int64_t M = s->M;
+  // the capacity-overflow word belongs to the step that starts here: an earlier step's report is not repeated
+  F_HIP(hipMemsetAsync(s->overflow, 0, sizeof(int32_t), c->stream));
   // landmarks in range of the true pose, in landmark order, as (r, phi) pairs: measure() returns
   // r_max + 1 for the others, which fast_slam() skips (:291).  Padded to a multiple of eight with readings
   // no feature is near.

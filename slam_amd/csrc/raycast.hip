@@ -96,19 +96,37 @@ __device__ inline double wave_sum(double v) {
                               (unsigned int)__builtin_amdgcn_readlane((int)__double_as_longlong(v), 63));
 }
 
-// float32 sum over the 64 lanes, valid in every lane
-__device__ inline float wave_sum_f32(float v) {
-  auto shifted = [](float x, auto ctrl, auto rmask) {
-    return __int_as_float(MCL_DPP_I32(0, __float_as_int(x), decltype(ctrl)::value, decltype(rmask)::value));
-  };
-  using std::integral_constant;
-  v += shifted(v, integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{});
-  v += shifted(v, integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{});
-  v += shifted(v, integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{});
-  v += shifted(v, integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{});
-  v += shifted(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});
-  v += shifted(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+// 32-bit integer sum over the 64 lanes, valid in every lane
+__device__ inline int wave_sum_i32(int v) {
+  v += MCL_DPP_I32(0, v, 0x111, 0xf);
+  v += MCL_DPP_I32(0, v, 0x112, 0xf);
+  v += MCL_DPP_I32(0, v, 0x114, 0xf);
+  v += MCL_DPP_I32(0, v, 0x118, 0xf);
+  v += MCL_DPP_I32(0, v, 0x142, 0xa);
+  v += MCL_DPP_I32(0, v, 0x143, 0xc);
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+// Sum over the 64 lanes of the lanes' log2 totals, valid in every lane, in FIXED POINT: the whole part of every
+// term in one 32-bit integer, its fraction in units of 2^-25 in another, both added exactly.  A float32 sum of 64
+// terms of a few tens each is good to 1e-6 of the terms, which shows where terms of either sign cancel to a
+// log-weight near zero -- the best particles; this one is good to 64 * 2^-26 = 1e-6 at worst (7e-8 on average)
+// whatever the terms' size, costs what a float64 sum over the lanes does, and does not depend on the order in
+// which lanes (or, with atomics, waves) are added.  Terms that are not finite, or beyond 2^20 in size, take the
+// float64 sum.
+constexpr double kFixedUnit = 33554432.0;   // 2^25
+__device__ inline void to_fixed(double v, int* whole, unsigned int* frac) {
+  const double fl = floor(v);
+  *whole = (int)fl;
+  *frac = (unsigned int)rint((v - fl) * kFixedUnit);   // [0, 2^25]: 64 of them fit 32 bits
+}
+__device__ inline double from_fixed(int whole, unsigned int frac) { return (double)whole + (double)frac * (1.0 / kFixedUnit); }
+__device__ inline double wave_sum_fixed(double v) {
+  if (__ballot(!(fabs(v) < 1048576.0)) != 0ull) return wave_sum(v);   // (also NaN)
+  int whole;
+  unsigned int frac;
+  to_fixed(v, &whole, &frac);
+  return from_fixed(wave_sum_i32(whole), (unsigned int)wave_sum_i32((int)frac));
 }
 
 // Bearing of (dx, dy) in [0, 2pi) (SIGNED: in (-pi, pi], one reflection less), float32, |error| < 1e-6 rad for finite
@@ -931,8 +949,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
         }
       }
       if (nfac) l2s += log2_of_product(prod);
-      // (64 lane totals of a few tens each: a float32 sum is good to 3e-7 of the result)
-      const double lsd = (double)wave_sum_f32((float)l2s) * 0.6931471805599453;
+      const double lsd = wave_sum_fixed(l2s) * 0.6931471805599453;
       if constexpr (IVONLY) {
         // (the output pointer from the argument block, like the map fields above, instead of a scalar pair spilled
         // across the loop: -1.5 % of the launch.  KArgs repeats the head of this kernel's argument list, in order.)
@@ -1185,13 +1202,15 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
   } else if (dtype == MCLHIP_F32) {
     if (product) MCL_RAY(float, false, true);
     else if (split) {
-      MCL_HIP(c, hipMemsetAsync(c->redo_count, 0, kSubLists * sizeof(uint32_t), c->stream));
-      P.redo_list = c->redo_list; P.redo_count = c->redo_count;
-      timing_begin(c, 0);
       // blocks b, b + 64, ... of the first launch append to list b % 64: what one list can receive is bounded by the
       // particles those blocks serve
       P.sub_cap = ((n + wpb - 1) / wpb + kSubLists - 1) / kSubLists * wpb;
       if ((int64_t)P.sub_cap * kSubLists > c->redo_cap + mclhip_ctx::kRedoSlack) return fail(c, MCLHIP_E_LIMIT, "left-over list too small");
+      const size_t lds_b = ray_lds_bytes(P.B, P.G, P.NB, false, kWavesPerBlock, 0, 0, 0, 0, 0);   // the second launch's
+      if (lds_b > 160 * 1024) return fail(c, MCLHIP_E_LIMIT, "beam table does not fit the kernel's LDS budget");
+      MCL_HIP(c, hipMemsetAsync(c->redo_count, 0, kSubLists * sizeof(uint32_t), c->stream));
+      P.redo_list = c->redo_list; P.redo_count = c->redo_count;
+      timing_begin(c, 0);
       const bool even = c->iv_uniform, same = c->iv_cmin == c->iv_cmax;     // equally wide intervals; as many per sector
       if (cap == 192 && even && same && c->iv_cmax == 5) MCL_RAY_U(float, false, false, false, true, kWavesPerBlock, true, false, 192, 5);
       else if (cap == 192 && even) MCL_RAY_U(float, false, false, false, true, kWavesPerBlock, true, false, 192, -1);
@@ -1209,8 +1228,6 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
       // the latency of one particle per wave, so it wants many waves rather than long strides)
       P.redo_list = nullptr; P.redo_count = nullptr; P.list = c->redo_list; P.list_count = c->redo_count;
       P.iv_NE = 0; P.iv_cmax = 0;
-      const size_t lds_b = ray_lds_bytes(P.B, P.G, P.NB, false, kWavesPerBlock, 0, 0, 0, 0, 0);
-      if (lds_b > 160 * 1024) return fail(c, MCLHIP_E_LIMIT, "beam table does not fit the kernel's LDS budget");
       int64_t blocks_b = (n + kWavesPerBlock - 1) / kWavesPerBlock;
       if (blocks_b > MCL_MAX_BLOCKS) blocks_b = MCL_MAX_BLOCKS;
       blocks_b = (blocks_b + kSubLists - 1) / kSubLists * kSubLists;      // the same number of blocks behind every list

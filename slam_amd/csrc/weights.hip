@@ -1015,8 +1015,8 @@ struct StoreU32 {
 };
 
 // slices[4d .. 4d+3] = first row, last row (local; first > last: none), number of drawn rows among them, and where
-// they start in the send buffer, for destination rank d; counts[d] = that number, counts[world] = the overflow flag
-// of the record merge.  Destination d owns the positions [first[d], first[d+1]); it needs the rows j with
+// they start in the send buffer, for destination rank d; counts[d] = that number, counts[world] = 1 when nothing
+// was planned (the record merge overflowed, or the plan would not fit n + world rows).  Destination d owns the positions [first[d], first[d+1]); it needs the rows j with
 // G[j] > first[d] (some position of d at or after the row's first drawer... its range ends beyond d's start) and
 // G[j-1] <= last position of d.
 __global__ void plan_slices_kernel(const int64_t* __restrict__ G, const unsigned int* __restrict__ S, int64_t n,
@@ -1044,9 +1044,21 @@ __global__ void plan_slices_kernel(const int64_t* __restrict__ G, const unsigned
   }
   __syncthreads();
   if (d == 0) {
+    // With exact running sums the draw ends ascend and the slices hold every local row once and the rows at the rank
+    // boundaries twice: at most n + world rows, which is what the callers' send buffers hold.  After a record merge
+    // that ran out of room the running sums are not the exact ones and the draw ends need not ascend: then, or
+    // whenever the plan would exceed that bound, nothing is planned (no row is packed) and the overflow word is set,
+    // so that the caller finishes the step another way.
+    int64_t total = 0;
+    for (int k = 0; k < lay.world; ++k) total += s_cnt[k];
+    const bool refuse = (meta && meta[3]) || total > n + (int64_t)lay.world;
     int64_t off = 0;
-    for (int k = 0; k < lay.world; ++k) { slices[4 * k + 3] = off; off += s_cnt[k]; }
-    counts[lay.world] = meta ? (int64_t)meta[3] : 0;
+    for (int k = 0; k < lay.world; ++k) {
+      if (refuse) { slices[4 * k + 2] = 0; counts[k] = 0; s_cnt[k] = 0; }
+      slices[4 * k + 3] = off;
+      off += s_cnt[k];
+    }
+    counts[lay.world] = refuse ? 1 : 0;
   }
 }
 

@@ -476,6 +476,9 @@ class ShardedFastSLAM:
                              self.t_plan.data_ptr() + 8 * (world + 1))
         plan = yield ("all_gather_read", self.t_all_plan, self.t_plan)
         plan = plan.reshape(world, world + 4)
+        # Either error leaves the step half done on every rank (poses advanced, no particle resampled): the filter
+        # has to be set up again -- with a larger capacity, or a larger RECORD_CAP -- before it is stepped further.
+        # (On a record overflow the plan holds no rows: nothing was packed or updated.)
         if plan[:, world].any() or plan[:, world + 3].any():
             raise _lib.MclHipError("more irregular records on a rank than the fixed exchange holds (ShardedFastSLAM.RECORD_CAP)")
         if plan[:, world + 2].any():

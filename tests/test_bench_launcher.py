@@ -27,10 +27,33 @@ def test_launcher_starts_two_ranks_without_a_gpu():
 
 
 def test_launcher_refuses_more_ranks_than_gpus():
-    import torch
-    n = torch.cuda.device_count() + 2
-    rc, out, err = _run(["--gpus", str(n)])
-    assert rc != 0 and out.strip() == "" and "GPU(s) visible" in err
+    """The launcher counts GPUs from the driver's topology files (no torch, no HIP in the parent) and refuses at once;
+    where there is no topology to read (a box without the driver) the ranks fail by themselves and it reports that."""
+    sys.path.insert(0, ROOT)
+    import bench
+    have = bench.visible_gpus()
+    rc, out, err = _run(["--gpus", str((have or 0) + 2)])
+    assert rc != 0 and out.strip() == ""
+    if have is not None:
+        assert "GPU(s) visible" in err
+
+
+def test_gpu_count_from_topology_files(tmp_path, monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    for k, simd in enumerate((0, 1024, 1024, 0, 1024)):            # CPU nodes have no SIMDs
+        d = tmp_path / str(k)
+        d.mkdir()
+        (d / "properties").write_text("cpu_cores_count %d\nsimd_count %d\nmem_banks_count 1\n" % (0 if simd else 64, simd))
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert bench.visible_gpus(str(tmp_path)) == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.visible_gpus(str(tmp_path)) == 2
+    assert bench.visible_gpus(str(tmp_path / "nothing")) is None
+    src = open(BENCH).read()
+    head = src[src.index("def launch_ranks"):src.index("def cpu_baseline")]
+    assert "import torch" not in head                            # the parent of the ranks stays clear of the GPU runtime
 
 
 def test_a_failing_rank_fails_the_launcher():

@@ -736,7 +736,5 @@ def _random_beam_set_case(seed, f64):
         return
     if fin.any():
         diff = np.abs(logw[fin] - lwo[fin])
-        size = np.sum(np.abs(np.log(P[fin])), axis=1)
-        # 1e-5 of the log-weight, or (where terms of either sign cancel) 1e-6 of what was summed
-        assert np.all((diff <= 1e-5 * np.maximum(1.0, np.abs(lwo[fin]))) | (diff <= 1e-6 * size)), (kind, B, half, M, diff.max())
+        assert np.all(diff <= 1e-5 * np.maximum(1.0, np.abs(lwo[fin]))), (kind, B, half, M, diff.max())   # 1e-5 of the log-weight
     ctx.close()

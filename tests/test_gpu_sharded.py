@@ -379,6 +379,49 @@ def test_device_driven_fastslam_of_several_ranks_equals_one_context(sizes):
     assert sent <= steps * (M + len(sizes) ** 2)
 
 
+def _fs_overflow_fn(rank, world, dist, sizes):
+    """One device-driven FastSLAM step of several ranks with room for a single irregular record per rank."""
+    import torch
+    from oracle import fastslam_oracle as F
+    from slam_amd import _lib
+    from slam_amd.sharded import ShardedFastSLAM
+    torch.cuda.set_device(0)
+    ShardedFastSLAM.RECORD_CAP = 1
+    M, W = sum(sizes), len(sizes)
+    filt = [ShardedFastSLAM.for_layout(_lib.Context(0, _lib.F64), k, sizes, 16) for k in range(W)]
+
+    def settle():
+        for f in filt:
+            f.ctx.sync()
+        torch.cuda.synchronize()
+
+    (ut, tr, tp, tv, ints, nrm, r) = _fs_inputs(M, 1)[0]
+    gens = []
+    for k, f in enumerate(filt):
+        sl = slice(f.firsts[k], f.firsts[k + 1])
+        f.t_send.fill_(-7.0)
+        gens.append(f._device_step(ut[0], ut[1], F.DT, F.ALPHA, tr, tp, tv, ints[sl], nrm[sl], r, 0))
+    raised = ""
+    try:
+        _run_lockstep(torch, gens, settle)
+    except _lib.MclHipError as e:
+        raised = str(e)
+    settle()
+    return {"raised": raised, "planned": [f.t_plan[:W + 1].cpu().numpy().tolist() for f in filt],
+            "send_untouched": [bool((f.t_send == -7.0).all().item()) for f in filt]}
+
+
+def test_device_driven_fastslam_plans_nothing_after_a_record_overflow():
+    """After a record merge that ran out of room the running sums are not the exact ones and the draw ends need not
+    ascend: the plan must then hold no row at all (nothing is written to the fixed-size send buffer, no particle is
+    updated) and carry the overflow word, which the driver turns into an error."""
+    res = run_ranks(_fs_overflow_fn, 1, (8192, 8192, 3000), backend="nccl")[0]
+    assert "RECORD_CAP" in res["raised"], res["raised"]
+    for plan in res["planned"]:
+        assert plan[:-1] == [0, 0, 0] and plan[-1] == 1, plan
+    assert all(res["send_untouched"])
+
+
 def _fs_rccl_rank_fn(rank, world, dist, M, steps):
     import torch
     from oracle import fastslam_oracle as F

@@ -1,7 +1,10 @@
 """mclhip_raycast_static -- the sector query for callers that cannot allocate device memory -- against
 mclhip_raycast, through the C ABI: ranges and hit cells bit for bit, on two calls in a row (the second with fewer
 poses, so stale contents of the shared device array would show), then after a change of map and sensor, and the
-limits."""
+limits; that the call leaves the device's free memory as it found it; and two contexts driven from two threads."""
+import ctypes
+import threading
+
 import numpy as np
 import pytest
 
@@ -70,3 +73,71 @@ def test_static_stage_query_matches_the_allocating_one():
         ctx3.raycast(P2, static=True)
     for c in (ctx, ctx2, ctx3):
         c.close()
+
+
+def _free_device_bytes():
+    """hipMemGetInfo of the current device, asked of the HIP runtime the library itself is linked against."""
+    hip = ctypes.CDLL("libamdhip64.so")
+    free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+    return free.value
+
+
+def test_static_stage_query_allocates_no_device_memory():
+    from slam_amd import _lib as L
+    from slam_amd import workload as W
+    rng = np.random.RandomState(3)
+    grid = W.synthetic_map(256)
+    ctx = L.Context(0, L.F64)
+    ctx.set_map(grid, W.RES, W.RES)
+    _sensor(ctx, W.beam_angles(16))
+    P = np.stack([rng.uniform(0, 38, 4096), rng.uniform(0, 38, 4096), rng.uniform(-3, 3, 4096)], 1)
+    ctx.raycast(P, static=True)                       # first call: whatever the runtime sets up lazily happens here
+    ctx.sync()
+    before = _free_device_bytes()
+    low = before
+    for n in (4096, 1, 300):
+        ctx.raycast(P[:n], static=True)
+        low = min(low, _free_device_bytes())
+    assert low == before, (before, low)
+    ctx.raycast(P)                                    # the allocating entry point, for contrast, frees what it took
+    assert _free_device_bytes() == before
+    ctx.close()
+
+
+def test_two_threads_with_a_context_each_share_the_static_array():
+    """Two contexts on one GPU, each driven by its own thread: the calls take turns on the device's array (a mutex per
+    device inside the library), so neither sees the other's poses or ranges."""
+    from slam_amd import _lib as L
+    from slam_amd import workload as W
+    rng = np.random.RandomState(17)
+    jobs = []
+    for k, (side, beams, n) in enumerate(((256, 16, 2000), (128, 45, 1400))):
+        grid = W.synthetic_map(side, seed=40 + k)
+        ctx = L.Context(0, L.F64)
+        ctx.set_map(grid, W.RES, W.RES)
+        _sensor(ctx, W.beam_angles(beams))
+        ext = side * W.RES
+        P = np.stack([rng.uniform(0, ext, n), rng.uniform(0, ext, n), rng.uniform(-3, 3, n)], 1)
+        jobs.append((ctx, P, ctx.raycast(P)))
+    bad, errors = [0, 0], []
+
+    def work(k):
+        ctx, P, (R, Hc) = jobs[k]
+        try:
+            for _ in range(40):
+                Rs, Hs = ctx.raycast(P, static=True)
+                if not (np.array_equal(R, Rs) and np.array_equal(Hc, Hs)):
+                    bad[k] += 1
+        except Exception as e:           # noqa: BLE001 -- reported by the assertion below
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert bad == [0, 0], bad
+    for ctx, _, _ in jobs:
+        ctx.close()
