@@ -348,6 +348,10 @@ def main():
     n_mot, ms_mot = ctx.timing_get(1)
     n_res, ms_res = ctx.timing_get(2)
     n_left, ms_left = ctx.timing_get(5)      # the sector query's second launch (particles the first left over), if any
+    try:
+        left_over, _ = ctx.timing_get(6)
+    except _lib.MclHipError:                 # a library build without the count
+        left_over = None
     ctx.timing_enable(False)
 
     if rank == 0:
@@ -382,6 +386,7 @@ def main():
                           "note": "only rows that some position draws travel (48 B each)"}
                          if filt.collective else None),
             "kernel_ms": {"raycast": ray_ms, "raycast_leftover_launch": (ms_left / n_left) if n_left else None,
+                          "raycast_leftover_particles": left_over,
                           "motion": ms_mot / max(n_mot, 1),
                           "normalise+resample+gather": ms_res / max(n_res, 1)},
         }

@@ -197,6 +197,7 @@ static int ensure_capacity(mclhip_ctx* c, int64_t M) {
   MCL_TRY(dev_alloc(c, &c->redo_list, (M + mclhip_ctx::kRedoSlack) * sizeof(int32_t)));
   MCL_TRY(dev_alloc(c, &c->redo_count, 64 * sizeof(uint32_t)));
   c->redo_cap = M;
+  if (c->dtype == MCLHIP_F32) MCL_TRY(dev_alloc(c, &c->qrec, (size_t)M * sizeof(QueryRecord)));
   if (c->noise) { (void)hipFree(c->noise); c->noise = nullptr; }
   c->cap = M;
   return MCLHIP_OK;
@@ -249,7 +250,21 @@ static MotionParams make_motion_params(const mclhip_ctx* c, double v, double ome
   mp.book = 0;
   mp.seed = seed;
   mp.index0 = c->first_index;
+  mp.qp.out = nullptr;
   return mp;
+}
+
+// The motion kernel can leave, per particle, what the interval-only sector query needs (QueryRecord): float32 state,
+// a beam table that has sector intervals, neighbourhood lists built.
+void make_query_prep(const mclhip_ctx* c, QueryPrep& qp) {
+  qp.out = nullptr;
+  if (c->dtype != MCLHIP_F32 || c->iv_NE <= 0 || !c->qrec || !c->nbr_off || c->ring_dirty) return;
+  qp.out = c->qrec;
+  qp.nbr_off = c->nbr_off;
+  qp.ETW = c->ETW << kQueryShift; qp.ETH = c->ETH << kQueryShift; qp.rtx = c->rtx << kQueryShift; qp.rty = c->rty << kQueryShift;
+  qp.inv_res_xf = (float)(1.0 / c->res_x); qp.inv_res_yf = (float)(1.0 / c->res_y);
+  qp.th_mid = (float)c->iv_th_mid; qp.th_hi = (float)c->iv_th_hi;
+  qp.origin = (float)c->iv_origin;
 }
 
 // the same for code outside this file (the sector query marks its own launches)
@@ -272,13 +287,16 @@ static int enqueue_sample(mclhip_ctx* c, double v, double omega, double dt, cons
   MotionParams mp = make_motion_params(c, v, omega, dt, alpha, noise_mode, seed);
   mp.ints_span = ints_span;
   const int a = c->cur;
+  // log-weights from the float32 mixture: the query may run as the interval-only kernel, which reads the motion
+  // kernel's records (launch_raycast decides; records it does not use cost 32 bytes per particle of writes)
+  if (!want_product && !d_range_noise && !(rn_sigma > 0.0) && c->zmeas_ok) make_query_prep(c, mp.qp);
   span_begin(c, spans, 1);
   MCL_TRY(launch_motion(c, c->px[a], c->py[a], c->pth[a], c->pm, c->M, mp, c->noise, c->dtype));
   span_end(c, spans);
   // (timed inside: group 0 around its kernel, or around the first of its two kernels and group 5 around the second)
   // the raw product is only formed when somebody will read it: it costs one dependent multiply per beam
   MCL_TRY(launch_raycast(c, c->px[a], c->py[a], c->pth[a], c->pm, c->M, c->dtype, want_product ? c->w[a] : nullptr,
-                         c->logw, nullptr, nullptr, d_range_noise, rn_sigma, seed));
+                         c->logw, nullptr, nullptr, d_range_noise, rn_sigma, seed, mp.qp.out));
   return MCLHIP_OK;
 }
 
@@ -356,7 +374,7 @@ void mclhip_destroy(mclhip_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   fs_release(c);
-  void* ptrs[] = {c->obst, c->freeb, c->tile_off, c->cells, c->nbr_off, c->nbr_cells, c->tab_sorted, c->tab_orig, c->perm, c->inv_perm, c->lut, c->relx, c->iv_edge, c->iv_beam, c->iv_lut, c->iv_ends, c->redo_list, c->redo_count, c->zt, c->etalam, c->zmeas_stage, c->ring,
+  void* ptrs[] = {c->obst, c->freeb, c->tile_off, c->cells, c->nbr_off, c->nbr_cells, c->tab_sorted, c->tab_orig, c->perm, c->inv_perm, c->lut, c->relx, c->iv_edge, c->iv_beam, c->iv_lut, c->iv_ends, c->redo_list, c->redo_count, c->qrec, c->zt, c->etalam, c->zmeas_stage, c->ring,
                   c->px[0], c->px[1], c->py[0], c->py[1], c->pth[0], c->pth[1], c->w[0], c->w[1], c->logw, c->pm,
                   c->sx, c->sy, c->sth, c->sw, c->chunk_sums, c->scal, c->cdf_approx, c->cdf_exact, c->kscan,
                   c->fscan, c->blk_a, c->blk_b, c->irr, c->bases, c->idx, c->noise, c->counters, c->range_noise, c->inj_rows, c->stamps,
@@ -1388,6 +1406,14 @@ int mclhip_timing_get(mclhip_ctx* c, int which, int64_t* launches, double* total
     (void)hipMemcpy(&v, c->stamps + (which - 100), sizeof(v), hipMemcpyDeviceToHost);
     if (launches) *launches = (int64_t)v;
     if (total_ms) *total_ms = (double)v;
+    return MCLHIP_OK;
+  }
+  if (c && which == 6) {   // particles the last two-launch sector query left to its second launch, as the host last saw it
+    uint64_t left = 0;
+    if (c->redo_hint)
+      for (int k = 0; k < 64; ++k) left += reinterpret_cast<volatile uint32_t*>(c->redo_hint)[k];
+    if (launches) *launches = (int64_t)left;
+    if (total_ms) *total_ms = 0.0;
     return MCLHIP_OK;
   }
   if (!c || which < 0 || which > 5) return MCLHIP_E_ARG;

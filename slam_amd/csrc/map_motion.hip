@@ -244,7 +244,36 @@ __global__ __launch_bounds__(256) void motion_kernel(T* __restrict__ xs, T* __re
   xs[i] = sx;
   ys[i] = sy;
   ths[i] = st;
-  pm[i] = (!mp.book && on_free_cell((double)sx, (double)sy, mp)) ? 1 : 0;
+  const bool fr = !mp.book && on_free_cell((double)sx, (double)sy, mp);
+  pm[i] = fr ? 1 : 0;
+  if (mp.qp.out) {
+    // the particle's record for the interval-only sector query (see QueryRecord): its tile's slice of neighbourhood
+    // cells -- the tile from a float32 product, off by one at an exact tile edge at worst, which the lists' cell of
+    // slack covers -- and whether its heading is one that path serves (also false for NaN / infinite headings)
+    const QueryPrep& q = mp.qp;
+    QueryRecord rec;
+    rec.x = (float)sx; rec.y = (float)sy; rec.th = (float)st;
+    rec.tho = (rec.th + q.origin) * 0.15915494309189535f;
+    const bool served = fabsf(rec.th - q.th_mid) <= q.th_hi;
+    const float fxc = rec.x * q.inv_res_xf, fyc = rec.y * q.inv_res_yf;
+    const bool pose_ok = (fabsf(fxc) < 1.0e6f) && (fabsf(fyc) < 1.0e6f);   // far outside any map, or NaN: no tile
+    uint32_t first = 0u, n_cells = 0u;
+    if (pose_ok && served) {
+      const int ex = (((int)floorf(fxc)) >> (3 - kQueryShift)) + q.rtx, ey = (((int)floorf(fyc)) >> (3 - kQueryShift)) + q.rty;
+      if (ex >= 0 && ex < q.ETW && ey >= 0 && ey < q.ETH) {
+        const uint32_t* no = q.nbr_off + ((size_t)ey * q.ETW + ex);
+        first = no[0];
+        n_cells = no[1] - first;
+      }
+    }
+    rec.first = first; rec.n_cells = n_cells;
+    rec.flags = (fr ? 1u : 0u) | (served ? 2u : 0u);
+    rec.gap0 = rec.gap1 = rec.gap2 = rec.gap3 = rec.gap4 = rec.gap5 = rec.gap6 = rec.gap7[0] = rec.gap7[1] = 0u;
+    uint4* dst = reinterpret_cast<uint4*>(&q.out[i]);
+    const uint4* src = reinterpret_cast<const uint4*>(&rec);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dst[k] = src[k];
+  }
 }
 
 // Initial particle cloud drawn on the device (mc_localization.py:173-219): rejection sampling of

@@ -105,6 +105,34 @@ struct RayParams {
   const double* g_thd;
 };
 
+// What the interval-only sector query needs of a particle, left by the motion kernel in one 64-byte record (one
+// cache line): the wave that serves the particle fetches it with scalar loads, a particle ahead, and starts on the
+// particle's list of cells without computing a tile or waiting for the tile's bounds (a dependent read from HBM per
+// particle).  Every field stands in a dword pair of its own ON PURPOSE: adjacent fields are fetched with one
+// multi-dword scalar load into an aligned register tuple, which the loop cannot keep reserved for a whole particle --
+// the compiler then copies the parts out at once and WAITS for the load where it is issued, not a particle later,
+// where it is used.  Single dwords land in whatever registers the loop holds them in.
+struct QueryRecord {
+  float x; uint32_t gap0;        // the pose as stored (float32 state)
+  float y; uint32_t gap1;
+  float th; uint32_t gap2;
+  float tho; uint32_t gap3;      // (heading + angle of interval edge 0) in turns: a bearing in turns minus this, its
+                                 // fraction taken, is the bearing's place on the circle of sector intervals
+  uint32_t first; uint32_t gap4; // the slice of RayParams::nbr_cells the particle has to look at ...
+  uint32_t n_cells; uint32_t gap5;   // ... and its length (whole batches of 64)
+  uint32_t flags; uint32_t gap6; // bit 0: the pose rounds to a free cell; bit 1: the heading is one the interval path serves
+  uint32_t gap7[2];
+};
+static_assert(sizeof(QueryRecord) == 64, "one cache line");
+struct QueryPrep {
+  QueryRecord* out;      // null: no records are written
+  const uint32_t* nbr_off;
+  int ETW, ETH, rtx, rty;
+  float inv_res_xf, inv_res_yf;
+  float th_mid, th_hi;   // |heading - th_mid| <= th_hi: served by the interval path (RayParams::iv_th_*)
+  float origin;          // RayParams::iv_origin
+};
+
 struct MotionParams {
   double v, omega, dt;
   double c1, c2, c3;     // b/6 for the three draws
@@ -116,6 +144,7 @@ struct MotionParams {
   int book;              // 1: Table 5.3 as printed (05_robot_motion/sample_motion_model_velocity.py:90-108): no straight-line branch, no map
   uint64_t seed;
   int64_t index0;        // global index of particle 0 (keys the device generator)
+  QueryPrep qp;          // records for the sector query that follows (float32 state, sector intervals), or out == null
 };
 
 }  // namespace mcl
@@ -171,6 +200,7 @@ struct mclhip_ctx {
   // particles (structure of arrays; pose arrays are float or double by dtype)
   int64_t M = 0, cap = 0;
   int32_t* redo_list = nullptr; uint32_t* redo_count = nullptr; int64_t redo_cap = 0;   // particles the interval-only sector query left over
+  mcl::QueryRecord* qrec = nullptr;   // [cap] the motion kernel's records for the interval-only sector query
   static constexpr int64_t kRedoSlack = 64 * 16 * 2;   // the 64 lists are rounded up to whole blocks of waves
   // How many particles the interval-only launch left over last time (page-locked host copy of the 64 counters, written
   // by an asynchronous copy behind the second launch and read, without waiting, before the next query is enqueued --
@@ -288,7 +318,10 @@ void timing_begin(mclhip_ctx* c, int which);
 void timing_end(mclhip_ctx* c);
 int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, const uint8_t* pm, int64_t n,
                    int dtype, double* w_out, double* logw_out, double* ranges_out, int32_t* hits_out,
-                   const double* range_noise = nullptr, double rn_sigma = 0.0, uint64_t rn_seed = 0);
+                   const double* range_noise = nullptr, double rn_sigma = 0.0, uint64_t rn_seed = 0,
+                   const QueryRecord* qrec = nullptr);
+// fills mp.qp so that the motion kernel leaves the records of the sector query that follows (or out = null: none)
+void make_query_prep(const mclhip_ctx* c, QueryPrep& qp);
 int launch_mean_weight(mclhip_ctx* c);
 int launch_sequential_total(mclhip_ctx* c);   // c->cdf_exact = strictly sequential running sum of the live weights
 void fs_release(mclhip_ctx* c);

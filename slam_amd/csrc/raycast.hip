@@ -155,6 +155,29 @@ __device__ inline float bearing_f32(float dy, float dx) {
   return r;
 }
 
+// The same in TURNS, in (-1/2, 1/2]: the polynomial's coefficients divided by 2 pi, reflections about 1/4 and 1/2.
+// For the interval-only kernel, which wants the bearing's place on a circle cut into sector intervals: the fraction
+// of (bearing - heading - first edge), all in turns, is that place -- one subtraction and v_fract_f32 instead of two
+// subtractions, a product, a floor and a fused multiply-add.  |error| < 2e-7 turns.
+__device__ inline float bearing_turns_f32(float dy, float dx) {
+  const float ax = fabsf(dx), ay = fabsf(dy);
+  const float mx = fmaxf(fmaxf(ax, ay), 1.0e-30f), mn = fminf(ax, ay);
+  const float t = mn * __builtin_amdgcn_rcpf(mx);
+  const float s = t * t;
+  float p = (float)(-0.004054124001413584 * 0.15915494309189535);
+  p = fmaf(p, s, (float)(0.021861203014850616 * 0.15915494309189535));
+  p = fmaf(p, s, (float)(-0.05590951070189476 * 0.15915494309189535));
+  p = fmaf(p, s, (float)(0.09641963243484497 * 0.15915494309189535));
+  p = fmaf(p, s, (float)(-0.13908521831035614 * 0.15915494309189535));
+  p = fmaf(p, s, (float)(0.19946539402008057 * 0.15915494309189535));
+  p = fmaf(p, s, (float)(-0.33329856395721436 * 0.15915494309189535));
+  p = fmaf(p, s, (float)(0.9999993443489075 * 0.15915494309189535));
+  float r = t * p;
+  r = ay > ax ? 0.25f - r : r;
+  r = dx < 0.0f ? 0.5f - r : r;
+  return copysignf(r, dy);
+}
+
 // float64 bearing in [0, 2pi) exactly as the reference forms it (mc_localization.py:133-135).
 // Kept out of line: it runs for a few cells in a thousand, and inlined its two dozen polynomial
 // constants would sit in registers of the hot loop.
@@ -240,7 +263,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
                           amdgpu_waves_per_eu(MCL_RAY_OCC(T, GRID, WPB, FAST, IVONLY), MCL_RAY_OCC(T, GRID, WPB, FAST, IVONLY)))) void raycast_kernel(
     RayParams P, const T* __restrict__ xs, const T* __restrict__ ys, const T* __restrict__ ths,
     const uint8_t* __restrict__ pm, int64_t n, double* __restrict__ w_out, double* __restrict__ logw_out,
-    double* __restrict__ ranges_out, int32_t* __restrict__ hits_out) {
+    double* __restrict__ ranges_out, int32_t* __restrict__ hits_out, const QueryRecord* __restrict__ qrec) {
   // (P must stay the first argument and the list up to logw_out as it is: the interval-only instantiation reads both
   // through the argument block's address, see Pk and KArgs below)
   extern __shared__ __align__(16) unsigned char smem[];
@@ -363,6 +386,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
   const float iv_nearf = (float)kEdgeEps + (UNIF != 0 ? 4e-6f : 3e-6f);     // closer than this to a sector edge, float32 does not decide
   const float iv_near_uf = 0.5f - iv_nearf * (float)((double)P.iv_NE / kTwoPi);   // UNIF: the same band in interval widths, from the middle
   const float iv_inv_wf = (float)((double)P.iv_NE / kTwoPi);   // UNIF: intervals per radian
+  const float iv_nf = (float)P.iv_NE;                          // ... and per turn
 
   const unsigned long long r2max_bits = (unsigned long long)__double_as_longlong(P.r2max);
   const float disk_r = (float)(P.z_max * (1.0 + 1e-5) + 0.02 * (P.res_x < P.res_y ? P.res_x : P.res_y));
@@ -374,7 +398,6 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
   const double reach = P.half + 2.0 * kEdgeEps;   // candidate window half-width
   const double inv_two_pi = 1.0 / kTwoPi;
   const double inv_res_x = 1.0 / P.res_x, inv_res_y = 1.0 / P.res_y;
-  const float inv_res_xf = (float)inv_res_x, inv_res_yf = (float)inv_res_y;
   const float reachf = (float)reach, inv_bwf = (float)P.inv_bw, ext_minf = (float)P.ext_min;
   const float ts_minf = (float)P.ts_min, spanf = (float)span, inv_two_pif = (float)inv_two_pi;
   const int G = P.G, NX = P.G + B;
@@ -404,8 +427,21 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
   };
   T nx = (T)0, ny = (T)0, nth = (T)0;
   unsigned char npm = 0;
+  // IVONLY: everything about the next particle comes in the motion kernel's record (one eight-dword scalar load)
+  float n_tho = 0.0f;
+  unsigned int n_first = 0u, n_ncells = 0u, n_flags = 0u;
+  auto fetch_next = [&]() {
+    if constexpr (IVONLY) {
+      const QueryRecord& r = qrec[p_next];
+      nx = (T)r.x; ny = (T)r.y; nth = (T)r.th; n_tho = r.tho;
+      n_first = r.first; n_ncells = r.n_cells; n_flags = r.flags;
+    } else {
+      nx = xs[p_next]; ny = ys[p_next]; nth = ths[p_next];
+      if (!STAGE && !GRID) npm = pm[p_next];
+    }
+  };
   bool have = next_particle();
-  if (have) { nx = xs[p_next]; ny = ys[p_next]; nth = ths[p_next]; if (!STAGE && !GRID) npm = pm[p_next]; }
+  if (have) fetch_next();
   bool entry_by_entry = false;   // the particle at hand is being done again without sector intervals
   while (have) {
     STAMP(7);
@@ -414,11 +450,13 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
     // (one instruction) instead of being kept as 64-bit masks in scalar registers that spill
     int lane = lane0;
     if constexpr (!GRID) asm volatile("" : "+v"(lane));
+    const float tho = n_tho;
     const double x = (double)nx, y = (double)ny, th = (double)nth;
-    const bool on_free = npm != 0;
+    const bool on_free = IVONLY ? (n_flags & 1u) != 0u : npm != 0;
     // headings for which the reference's predicate is the circular one take the interval path (wave-uniform); a
     // particle is done again entry by entry when a cell on a sector edge cannot be filed under intervals (see below)
-    const bool use_iv = IVK && IVN > 0 && !entry_by_entry && fabsf((float)th - iv_th_midf) <= iv_th_hif;
+    const bool use_iv = IVONLY ? (n_flags & 2u) != 0u
+                               : (IVK && IVN > 0 && !entry_by_entry && fabsf((float)th - iv_th_midf) <= iv_th_hif);
     entry_by_entry = false;
     bool lane_redo = false;
     bool lane_parked = false;   // this lane has parked a cell
@@ -432,26 +470,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
     // the particle's slice of neighbourhood cells; NaN / infinite headings match no beam
     unsigned int first_cell = 0u, n_cells = 0u;
     if constexpr (IVONLY) {
-      // the map fields straight from the argument block (the kernel's first argument), once per particle: one scalar
-      // load instead of six scalar registers held across the whole loop, which at eight waves per SIMD were spilled to
-      // vector lanes and read back for every particle (16 v_readlane: 0.71 -> 0.68 ms at 2^20 x 180; the same in the
-      // other instantiations measured no gain)
-      typedef const __attribute__((address_space(4))) RayParams* KP;
-      KP Pk = (KP)__builtin_amdgcn_kernarg_segment_ptr();
-      asm volatile("" : "+s"(Pk));
-      const int ETW_ = Pk->ETW, ETH_ = Pk->ETH, rtx_ = Pk->rtx, rty_ = Pk->rty;
-      const uint32_t* nbr_off_ = Pk->nbr_off;
-      // (float32 state: the tile index from a float32 product -- off by one at an exact tile edge at worst, which the
-      // lists' cell of slack covers, like the float64 product's rounding)
-      const float fxcf = (float)nx * inv_res_xf, fycf = (float)ny * inv_res_yf;
-      const bool pose_ok_ = (fabsf(fxcf) < 1.0e6f) && (fabsf(fycf) < 1.0e6f) && fabsf((float)nth) < INFINITY;
-      const int ex = (pose_ok_ ? ((int)floorf(fxcf)) >> (3 - kQueryShift) : 0) + rtx_;
-      const int ey = (pose_ok_ ? ((int)floorf(fycf)) >> (3 - kQueryShift) : 0) + rty_;
-      if (pose_ok_ && ex >= 0 && ex < ETW_ && ey >= 0 && ey < ETH_ && use_iv) {
-        const unsigned int* no = nbr_off_ + ((size_t)ey * ETW_ + ex);
-        first_cell = no[0];
-        n_cells = no[1] - first_cell;
-      }
+      // (the record holds the slice of the particle's tile; no cells for a particle this kernel does not serve)
+      first_cell = n_first;
+      n_cells = n_ncells;
     } else {
       const int ex = tcx + rtx, ey = tcy + rty;
       if (pose_ok && fabs(th) < INFINITY && ex >= 0 && ex < ETW && ey >= 0 && ey < ETH && (!IVONLY || use_iv)) {
@@ -476,22 +497,31 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
       bool hit = valid && r2 <= P.r2max;       // :127
       // (the interval path reduces the angle itself.  FAST: pose and cell coordinates are float32 numbers, so their
       // float32 difference is the float64 one rounded -- the same operand without two conversions)
-      const float aaf = FAST ? bearing_f32<IVONLY>((float)row * P.res_yf - yf, (float)col * P.res_xf - xf)
-                             : bearing_f32<IVONLY>((float)dy, (float)dx);
+      const float aaf = IVONLY ? bearing_turns_f32((float)row * P.res_yf - yf, (float)col * P.res_xf - xf)
+                               : (FAST ? bearing_f32<false>((float)row * P.res_yf - yf, (float)col * P.res_xf - xf)
+                                       : bearing_f32<false>((float)dy, (float)dx));
       const unsigned long long r2bits = (unsigned long long)__double_as_longlong(r2);
       if constexpr (IVK) {
         if (use_iv) {
           // the interval that holds the bearing: one minimum serves every beam whose sector spans it.  Only a
           // bearing within rounding of a sector edge goes through the beam-by-beam test below.
-          float a = (aaf - thf) - iv_originf;                         // in (-4 pi, 5 pi) for the headings of this path
-          a = fmaf(-6.2831853071795865f, floorf(a * 0.15915494309189535f), a);   // [0, 2 pi) up to rounding; the ends are edges
+          // the bearing's place on the circle that starts at interval edge 0: in turns, [0, 1), for the interval-only
+          // kernel; in radians, [0, 2 pi) up to rounding (the ends are edges), for the others
+          float a, place = 0.0f;
+          if constexpr (IVONLY) {
+            place = __builtin_amdgcn_fractf(aaf - tho);
+            a = place * 6.2831853071795865f;
+          } else {
+            a = (aaf - thf) - iv_originf;                             // in (-4 pi, 5 pi) for the headings of this path
+            a = fmaf(-6.2831853071795865f, floorf(a * 0.15915494309189535f), a);
+          }
           int m;
           float e0 = 0.0f, e1 = 0.0f, uf = 0.0f;
           if constexpr (UNIF != 0) {
-            // (a >= -1e-6 and the conversion truncates towards zero: only the upper end needs a clamp; NaN converts to 0.
-            // The product is within 4e-7 rad of the true place: the band below allows for it, and a bearing that lands
-            // one interval off is within the band of the edge between the two, which is what counts)
-            const float au = a * iv_inv_wf;
+            // (the place is not negative and the conversion truncates towards zero: only the upper end needs a clamp; NaN
+            // converts to 0.  The product is within 4e-7 rad of the true place: the band below allows for it, and a
+            // bearing that lands one interval off is within the band of the edge between the two, which is what counts)
+            const float au = IVONLY ? place * iv_nf : a * iv_inv_wf;
             m = (int)au;
             m = m > IVN - 1 ? IVN - 1 : m;
             uf = au - (float)m;        // place inside the interval, in interval widths
@@ -770,10 +800,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     have = next_particle();
-    if (have) {   // next pose in flight while this particle's weight is computed
-      nx = xs[p_next]; ny = ys[p_next]; nth = ths[p_next];
-      if (!STAGE && !GRID) npm = pm[p_next];
-    }
+    if (have) fetch_next();   // next pose in flight while this particle's weight is computed
     if constexpr (IVONLY) {
       // not for this kernel: the heading is outside the interval path's range, or a cell on a sector edge asked for
       // the entry-by-entry test; the particle is filed for the launch that follows
@@ -1118,7 +1145,7 @@ int launch_grid_update(mclhip_ctx* c, const double* d_x, const double* d_y, cons
                                      (int)lds));                                                                      \
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, P, d_x, d_y, d_th,                 \
                        (const uint8_t*)nullptr, n, (double*)nullptr, (double*)nullptr, (double*)nullptr,              \
-                       (int32_t*)nullptr);                                                                            \
+                       (int32_t*)nullptr, (const QueryRecord*)nullptr);                                               \
   } while (0)
   if (waves == 16) MCL_GRID(16);
   else if (waves == 12) MCL_GRID(12);
@@ -1131,7 +1158,7 @@ int launch_grid_update(mclhip_ctx* c, const double* d_x, const double* d_y, cons
 
 int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, const uint8_t* pm, int64_t n,
                    int dtype, double* w_out, double* logw_out, double* ranges_out, int32_t* hits_out,
-                   const double* range_noise, double rn_sigma, uint64_t rn_seed) {
+                   const double* range_noise, double rn_sigma, uint64_t rn_seed, const QueryRecord* qrec) {
   const bool product = w_out != nullptr;
   if (n <= 0) return MCLHIP_OK;
   RayParams P = make_ray_params(c);
@@ -1145,7 +1172,8 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
   // The float32-mixture path with sector intervals runs as two launches: the interval-only kernel, which files the
   // particles it does not serve (headings outside the interval path's range: 5 % of a uniform cloud), and the general
   // kernel over that list.  Together 0.9x ms instead of 1.05 ms at 2^20 x 180.
-  bool split = fast && P.iv_NE > 0 && c->redo_list && n <= c->redo_cap && pm != nullptr && c->split_mode != 0;
+  // (the interval-only kernel takes its particles from the records the motion kernel left)
+  bool split = fast && P.iv_NE > 0 && c->redo_list && n <= c->redo_cap && pm != nullptr && qrec != nullptr && c->split_mode != 0;
   if (split && c->split_mode < 0 && c->redo_hint) {
     // last time's left-over count (a hint, see mclhip_ctx::redo_hint)
     uint64_t left = 0;
@@ -1187,7 +1215,7 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
       MCL_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                      (int)lds));                                                                     \
     hipLaunchKernelGGL(kern, grid, block, lds, c->stream, P, (const TT*)x, (const TT*)y, (const TT*)th, pm, n, w_out, \
-                       logw_out, ranges_out, hits_out);                                                              \
+                       logw_out, ranges_out, hits_out, II ? qrec : (const QueryRecord*)nullptr);                     \
   } while (0)
   if (!stage && !split) timing_begin(c, 0);
   if (stage) {
@@ -1229,14 +1257,17 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
       P.redo_list = nullptr; P.redo_count = nullptr; P.list = c->redo_list; P.list_count = c->redo_count;
       P.iv_NE = 0; P.iv_cmax = 0;
       int64_t blocks_b = (n + kWavesPerBlock - 1) / kWavesPerBlock;
-      if (blocks_b > MCL_MAX_BLOCKS) blocks_b = MCL_MAX_BLOCKS;
+      // (two rounds of the blocks a chip holds: measured at 2^20 particles with 33000 left over, 16384 blocks 0.070 ms,
+      // 7168 0.067, 3584 0.063, 1792 0.062, 896 0.083)
+      if (blocks_b > 3584) blocks_b = 3584;
       blocks_b = (blocks_b + kSubLists - 1) / kSubLists * kSubLists;      // the same number of blocks behind every list
       {
         auto kern = raycast_kernel<float, false, false, false, kWavesPerBlock, false, true, false, true>;
         if (lds_b > 48 * 1024)
           MCL_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks_b), block.x == 64u * kWavesPerBlock ? block : dim3(64 * kWavesPerBlock), lds_b, c->stream, P,
-                           (const float*)x, (const float*)y, (const float*)th, pm, n, w_out, logw_out, ranges_out, hits_out);
+                           (const float*)x, (const float*)y, (const float*)th, pm, n, w_out, logw_out, ranges_out, hits_out,
+                           (const QueryRecord*)nullptr);
       }
       timing_end(c);
       if (c->redo_hint)
