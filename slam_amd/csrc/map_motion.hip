@@ -268,11 +268,11 @@ __global__ __launch_bounds__(256) void motion_kernel(T* __restrict__ xs, T* __re
     }
     rec.first = first; rec.n_cells = n_cells;
     rec.flags = (fr ? 1u : 0u) | (served ? 2u : 0u);
-    rec.gap0 = rec.gap1 = rec.gap2 = rec.gap3 = rec.gap4 = rec.gap5 = rec.gap6 = rec.gap7[0] = rec.gap7[1] = 0u;
+    rec.pad = 0u;
     uint4* dst = reinterpret_cast<uint4*>(&q.out[i]);
     const uint4* src = reinterpret_cast<const uint4*>(&rec);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) dst[k] = src[k];
+    dst[0] = src[0];
+    dst[1] = src[1];
   }
 }
 

@@ -105,25 +105,21 @@ struct RayParams {
   const double* g_thd;
 };
 
-// What the interval-only sector query needs of a particle, left by the motion kernel in one 64-byte record (one
-// cache line): the wave that serves the particle fetches it with scalar loads, a particle ahead, and starts on the
-// particle's list of cells without computing a tile or waiting for the tile's bounds (a dependent read from HBM per
-// particle).  Every field stands in a dword pair of its own ON PURPOSE: adjacent fields are fetched with one
-// multi-dword scalar load into an aligned register tuple, which the loop cannot keep reserved for a whole particle --
-// the compiler then copies the parts out at once and WAITS for the load where it is issued, not a particle later,
-// where it is used.  Single dwords land in whatever registers the loop holds them in.
+// What the interval-only sector query needs of a particle, left by the motion kernel in one 32-byte record: the
+// wave that serves the particle fetches it a particle ahead -- with two VECTOR loads in which every lane reads the
+// same 16 bytes, so that the values wait in vector registers behind the in-order vector-memory counter until they
+// are used (scalar loads share their counter with LDS: the first LDS read after one waits for it) -- and starts on
+// the particle's list of cells without computing a tile or waiting for the tile's bounds (a dependent read from HBM
+// per particle).
 struct QueryRecord {
-  float x; uint32_t gap0;        // the pose as stored (float32 state)
-  float y; uint32_t gap1;
-  float th; uint32_t gap2;
-  float tho; uint32_t gap3;      // (heading + angle of interval edge 0) in turns: a bearing in turns minus this, its
-                                 // fraction taken, is the bearing's place on the circle of sector intervals
-  uint32_t first; uint32_t gap4; // the slice of RayParams::nbr_cells the particle has to look at ...
-  uint32_t n_cells; uint32_t gap5;   // ... and its length (whole batches of 64)
-  uint32_t flags; uint32_t gap6; // bit 0: the pose rounds to a free cell; bit 1: the heading is one the interval path serves
-  uint32_t gap7[2];
+  float x, y, th;        // the pose as stored (float32 state)
+  float tho;             // (heading + angle of interval edge 0) in turns: a bearing in turns minus this, its fraction
+                         // taken, is the bearing's place on the circle of sector intervals
+  uint32_t first, n_cells;   // the slice of RayParams::nbr_cells the particle has to look at (whole batches of 64)
+  uint32_t flags;        // bit 0: the pose rounds to a free cell; bit 1: the heading is one the interval path serves
+  uint32_t pad;
 };
-static_assert(sizeof(QueryRecord) == 64, "one cache line");
+static_assert(sizeof(QueryRecord) == 32, "two 16-byte loads");
 struct QueryPrep {
   QueryRecord* out;      // null: no records are written
   const uint32_t* nbr_off;

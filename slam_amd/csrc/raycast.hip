@@ -352,9 +352,6 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
   // likewise these arguments.  (Not the pose pointers: one that has gone through this is no longer known to point to
   // read-only memory, its loads become vector loads and the pose lives in vector registers -- measured slower.)
   asm volatile("" : "+s"(logw_out), "+s"(n));
-  int32_t* redo_list = P.redo_list + (size_t)(blockIdx.x % kSubLists) * P.sub_cap;
-  uint32_t* redo_count = P.redo_count + (blockIdx.x % kSubLists);
-  asm volatile("" : "+s"(redo_list), "+s"(redo_count));
   const int lane0 = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: particle index, pose and slice bounds live in scalar registers
   unsigned long long* const rmin = s_rmin_all + (size_t)wv * TS;   // per extended-table entry (or per interval): bits of the smallest r2
@@ -371,16 +368,48 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
   auto flush_filed = [&](int lane_) {
     const int nf = __builtin_amdgcn_readfirstlane((int)filed_cnt[0]);
     if (nf > 0) {
+      // (the list's pointers from the argument block, here where they are needed: pointers the compiler can trace to
+      // the kernel's arguments are global ones -- a generic pointer's atomic would count against every counter)
+      typedef const __attribute__((address_space(4))) RayParams* KP;
+      KP Pk = (KP)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(Pk));
+      int32_t* const redo_list_ = Pk->redo_list + (size_t)(blockIdx.x % kSubLists) * Pk->sub_cap;
+      uint32_t* const redo_count_ = Pk->redo_count + (blockIdx.x % kSubLists);
       unsigned int base = 0u;
-      if (lane_ == 0) base = atomicAdd(redo_count, (unsigned int)nf);
+      if (lane_ == 0) base = atomicAdd(redo_count_, (unsigned int)nf);
       base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
-      if (lane_ < nf) redo_list[base + lane_] = (int32_t)filed[lane_];
+      if (lane_ < nf) redo_list_[base + lane_] = (int32_t)filed[lane_];
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): no store is left outstanding (see flush_out)
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       if (lane_ == 0) filed_cnt[0] = 0u;
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
   };
   if (IVONLY && lane0 == 0) { filed_cnt[0] = 0u; edge_cnt[0] = 0u; }
+  // IVONLY: the log-weights wait in LDS (where the other instantiations keep their ring of cells) and go to memory
+  // kOutBatch at a time.  A store per particle would be outstanding beside the loads that are fetched ahead -- the next
+  // particle's record and first batch of cells -- and the vector-memory counter only counts in order among accesses of
+  // ONE kind: with a store in flight every wait for one of those loads becomes a wait for all of them.
+  constexpr int kOutBatch = 16;
+  double* const outbuf = reinterpret_cast<double*>(ring);   // [kOutBatch]
+  int out_slot = 0;                  // wave-uniform
+  unsigned int out_mask = 0u;        // slots that hold a result (a particle left to the next launch has none)
+  int64_t out_base = 0;              // the particle behind slot 0
+  auto flush_out = [&](int lane_, int64_t step_) {
+    if (out_mask != 0u) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      struct KArgs { RayParams P; const void* xs; const void* ys; const void* ths; const void* pm; int64_t n; double* w_out; double* logw_out; };
+      typedef const __attribute__((address_space(4))) KArgs* KA;   // (repeats the head of this kernel's argument list, in order)
+      KA ka = (KA)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(ka));
+      double* const lo = ka->logw_out;
+      if (lane_ < kOutBatch && ((out_mask >> lane_) & 1u)) lo[out_base + (int64_t)lane_ * step_] = outbuf[lane_];
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): no store is left outstanding
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    out_mask = 0u;
+    out_slot = 0;
+  };
   unsigned long long* const imin = rmin;                               // the same array read as minima per sector interval
   const float iv_originf = (float)P.iv_origin, iv_inv_bwf = (float)((double)P.iv_NB / kTwoPi), iv_th_hif = (float)P.iv_th_hi, iv_th_midf = (float)P.iv_th_mid;
   const float iv_nearf = (float)kEdgeEps + (UNIF != 0 ? 4e-6f : 3e-6f);     // closer than this to a sector edge, float32 does not decide
@@ -428,13 +457,13 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
   T nx = (T)0, ny = (T)0, nth = (T)0;
   unsigned char npm = 0;
   // IVONLY: everything about the next particle comes in the motion kernel's record (one eight-dword scalar load)
-  float n_tho = 0.0f;
-  unsigned int n_first = 0u, n_ncells = 0u, n_flags = 0u;
+  // (ONE vector load: lane l reads dword l & 7 of the record, and the particle's turn starts with seven v_readlane that
+  // spread them into scalar registers.  A vector load waits behind the in-order vector-memory counter until its
+  // register is used; scalar loads share a counter with LDS, so the first LDS read after one would wait for it.)
+  unsigned int n_rec = 0u;
   auto fetch_next = [&]() {
     if constexpr (IVONLY) {
-      const QueryRecord& r = qrec[p_next];
-      nx = (T)r.x; ny = (T)r.y; nth = (T)r.th; n_tho = r.tho;
-      n_first = r.first; n_ncells = r.n_cells; n_flags = r.flags;
+      n_rec = reinterpret_cast<const unsigned int*>(qrec + p_next)[lane0 & 7];
     } else {
       nx = xs[p_next]; ny = ys[p_next]; nth = ths[p_next];
       if (!STAGE && !GRID) npm = pm[p_next];
@@ -442,20 +471,34 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
   };
   bool have = next_particle();
   if (have) fetch_next();
+  // IVONLY: the first batch of the next particle's list, fetched while the particle before it is still at its beams.
+  // (Four batches ahead -- a particle's whole list in flight at once -- measured -0.8 % in the global regime and
+  // +1.5 % in the tracking regime: the kernel does not wait for memory.)
+  unsigned int e_pref = 0u;
+  if constexpr (IVONLY) {
+    if (have && __builtin_amdgcn_readlane((int)n_rec, 5) != 0) e_pref = P.nbr_cells[(unsigned int)__builtin_amdgcn_readlane((int)n_rec, 4) + lane0];
+    // (nothing outstanding when the loop is entered: what the compiler must assume at the head of the loop is then what
+    // an iteration leaves behind -- the prefetched batch and the result's store -- and it waits where those are used)
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+  }
   bool entry_by_entry = false;   // the particle at hand is being done again without sector intervals
   while (have) {
     STAMP(7);
     p = p_next;
+    if constexpr (IVONLY) { if (out_slot == 0) out_base = p; }
     // the lane index is made opaque once per particle: comparisons against it are then formed where they are used
     // (one instruction) instead of being kept as 64-bit masks in scalar registers that spill
     int lane = lane0;
     if constexpr (!GRID) asm volatile("" : "+v"(lane));
-    const float tho = n_tho;
+    auto rec_word = [&](int k) { return IVONLY ? (unsigned int)__builtin_amdgcn_readlane((int)n_rec, k) : 0u; };
+    if constexpr (IVONLY) { nx = (T)__uint_as_float(rec_word(0)); ny = (T)__uint_as_float(rec_word(1)); nth = (T)__uint_as_float(rec_word(2)); }
+    const float tho = __uint_as_float(rec_word(3));
+    const unsigned int c_first = rec_word(4), c_ncells = rec_word(5), c_flags = rec_word(6);
     const double x = (double)nx, y = (double)ny, th = (double)nth;
-    const bool on_free = IVONLY ? (n_flags & 1u) != 0u : npm != 0;
+    const bool on_free = IVONLY ? (c_flags & 1u) != 0u : npm != 0;
     // headings for which the reference's predicate is the circular one take the interval path (wave-uniform); a
     // particle is done again entry by entry when a cell on a sector edge cannot be filed under intervals (see below)
-    const bool use_iv = IVONLY ? (n_flags & 2u) != 0u
+    const bool use_iv = IVONLY ? (c_flags & 2u) != 0u
                                : (IVK && IVN > 0 && !entry_by_entry && fabsf((float)th - iv_th_midf) <= iv_th_hif);
     entry_by_entry = false;
     bool lane_redo = false;
@@ -471,8 +514,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
     unsigned int first_cell = 0u, n_cells = 0u;
     if constexpr (IVONLY) {
       // (the record holds the slice of the particle's tile; no cells for a particle this kernel does not serve)
-      first_cell = n_first;
-      n_cells = n_ncells;
+      first_cell = c_first;
+      n_cells = c_ncells;
     } else {
       const int ex = tcx + rtx, ey = tcy + rty;
       if (pose_ok && fabs(th) < INFINITY && ex >= 0 && ex < ETW && ey >= 0 && ey < ETH && (!IVONLY || use_iv)) {
@@ -483,6 +526,14 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
     }
     const float xf = (float)x, yf = (float)y;
     const float thf = (float)th;
+    if constexpr (IVONLY) {
+      // the record after this one: asked for now (this particle's has been taken apart above), it arrives while this
+      // particle's cells are matched.  Unconditionally -- after the last particle its own record once more -- so that
+      // the number of loads in flight is the same on every path and the compiler can wait for the older one alone.
+      have = next_particle();
+      if (!have) p_next = p;
+      fetch_next();
+    }
 
     // one cell against the beam table
     auto match_cell = [&](unsigned int e, bool valid, int phase) {
@@ -683,7 +734,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
       // float64 test follows in match_cell) puts within z_max are queued in a 128-entry LDS
       // ring; whenever 64 are waiting they are matched together, so that the expensive part
       // runs with (almost) every lane busy although the slice holds many cells out of range.
-      unsigned int e_next = (lane < (int)n_cells) ? nbr_cells[first_cell + lane] : 0u;
+      unsigned int e_next = IVONLY ? e_pref : ((lane < (int)n_cells) ? nbr_cells[first_cell + lane] : 0u);
       STAMP(2);
       if constexpr (IVONLY) {
         // The interval path matches the fetched batches as they come: a list holds about 200 cells for the 130 within
@@ -691,13 +742,23 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
         // compaction of every batch does (0.884 -> 0.856 ms at 2^20 x 180).
         // (a list is whole batches of 64, padded with a cell out of every pose's reach: no per-lane bounds)
         const unsigned int n_list = (unsigned int)__builtin_amdgcn_readfirstlane((int)n_cells);
+        // (the loads go through the argument block's own pointer: one that has been made opaque is a generic pointer to
+        // the compiler, and loads through those count against the LDS counter as well)
+        // (the loads go through the argument block's own pointer: one that has been made opaque is a generic pointer to
+        // the compiler, and loads through those count against the LDS counter as well)
         for (unsigned int sb = 0; sb < n_list; sb += 64) {
           const unsigned int e = e_next;
           COUNT(0);
-          if (sb + 64 < n_list) e_next = nbr_cells[first_cell + sb + 64 + lane];   // next batch in flight
+          if (sb + 64 < n_list) e_next = P.nbr_cells[first_cell + sb + 64 + lane];   // next batch in flight
           match_cell(e, true, phase);
         }
         n_cells = 0u;
+        // Every batch has been consumed and the next record is needed now: an explicit vmcnt(0), on every path.  Without
+        // it the compiler cannot tell that no batch load is left outstanding and waits for ALL vector memory -- the
+        // prefetch below included -- wherever a register of the cell loop is written again.
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        // (the next record has arrived by now)
+        if (have && __builtin_amdgcn_readlane((int)n_rec, 5) != 0) e_pref = P.nbr_cells[(unsigned int)__builtin_amdgcn_readlane((int)n_rec, 4) + lane];
       }
       for (unsigned int sb = 0; sb < n_cells; sb += 64) {
         const unsigned int e = e_next;
@@ -799,8 +860,10 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
       for (int k = lane; k < P.iv_cmax; k += 64) imin[IVN + k] = imin[k];
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
-    have = next_particle();
-    if (have) fetch_next();   // next pose in flight while this particle's weight is computed
+    if constexpr (!IVONLY) {
+      have = next_particle();
+      if (have) fetch_next();   // next pose in flight while this particle's weight is computed
+    }
     if constexpr (IVONLY) {
       // not for this kernel: the heading is outside the interval path's range, or a cell on a sector edge asked for
       // the entry-by-entry test; the particle is filed for the launch that follows
@@ -809,6 +872,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
         if (lane == 0) { filed[nf] = (unsigned int)p; filed_cnt[0] = (unsigned int)(nf + 1); }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (nf + 1 == kFiled) flush_filed(lane);
+        if (++out_slot == kOutBatch) flush_out(lane, step);
         continue;
       }
     }
@@ -978,14 +1042,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
       if (nfac) l2s += log2_of_product(prod);
       const double lsd = wave_sum_fixed(l2s) * 0.6931471805599453;
       if constexpr (IVONLY) {
-        // (the output pointer from the argument block, like the map fields above, instead of a scalar pair spilled
-        // across the loop: -1.5 % of the launch.  KArgs repeats the head of this kernel's argument list, in order.)
-        struct KArgs { RayParams P; const void* xs; const void* ys; const void* ths; const void* pm; int64_t n; double* w_out; double* logw_out; };
-        typedef const __attribute__((address_space(4))) KArgs* KA;
-        KA ka = (KA)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(ka));
-        double* const lo = ka->logw_out;
-        if (lane == 0) lo[p] = on_free ? lsd : -INFINITY;
+        if (lane == 0) outbuf[out_slot] = on_free ? lsd : -INFINITY;
+        out_mask |= 1u << out_slot;
+        if (++out_slot == kOutBatch) flush_out(lane, step);
       } else if (lane == 0) logw_out[p] = on_free ? lsd : -INFINITY;
     } else {
       typedef T R;  // likelihood arithmetic follows the state dtype
@@ -1084,7 +1143,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     STAMP(6);
   }
-  if constexpr (IVONLY) flush_filed(lane0);
+  if constexpr (IVONLY) { flush_filed(lane0); flush_out(lane0, step); }
 #ifdef MCL_STAMPS
   if (lane0 == 0)
     for (int i = 0; i < 8; ++i) atomicAdd(&P.stamps[i], acc[i]);
