@@ -172,6 +172,12 @@ int mclhip_normalise(mclhip_ctx* ctx, int mode, double* sum_out);
  * idx_out (nullable): [M] source index of every resampled particle. */
 int mclhip_resample(mclhip_ctx* ctx, double r, int algo, int64_t* idx_out);
 
+/* mclhip_normalise + mclhip_resample (the whole of MCLocalization.resample,
+ * mc_localization.py:242-262) in one call and in the six kernels the fused update
+ * mclhip_step uses for them, on the weights the context holds: the same sum, the
+ * same normalised weights, the same indices, bit for bit.  sum_out, idx_out nullable. */
+int mclhip_normalise_resample(mclhip_ctx* ctx, int mode, double r, double* sum_out, int64_t* idx_out);
+
 /* One whole update = mclhip_sample + mclhip_normalise + mclhip_resample
  * (mc_localization.py:329-331) without intermediate host synchronisation.
  * mclhip_step_async returns after enqueueing; mclhip_sync waits. */

@@ -49,6 +49,7 @@ PROTOTYPES = {
     "mclhip_sample": (C.c_int, [_ctx_p, C.c_double, C.c_double, C.c_double, _dbl_p, _i16_p, C.c_uint64, _dbl_p]),
     "mclhip_normalise": (C.c_int, [_ctx_p, C.c_int, _dbl_p]),
     "mclhip_resample": (C.c_int, [_ctx_p, C.c_double, C.c_int, _i64_p]),
+    "mclhip_normalise_resample": (C.c_int, [_ctx_p, C.c_int, C.c_double, _dbl_p, _i64_p]),
     "mclhip_step": (C.c_int, [_ctx_p, C.c_double, C.c_double, C.c_double, _dbl_p, _i16_p, C.c_uint64, _dbl_p,
                               C.c_int, C.c_double]),
     "mclhip_step_async": (C.c_int, [_ctx_p, C.c_double, C.c_double, C.c_double, _dbl_p, C.c_uint64, _dbl_p, C.c_int,
@@ -339,6 +340,14 @@ class Context:
         idx = np.empty(self.num_particles(), np.int64) if want_idx else None
         self._ck(self.lib.mclhip_resample(self.h, float(r), int(algo), _p(idx, _i64_p)), "mclhip_resample")
         return idx
+
+    def normalise_resample(self, r, mode=W_PRODUCT, want_idx=True):
+        """mclhip_normalise + mclhip_resample as the fused update runs them; returns (sum of the weights, indices)."""
+        s = C.c_double(0.0)
+        idx = np.empty(self.num_particles(), np.int64) if want_idx else None
+        self._ck(self.lib.mclhip_normalise_resample(self.h, int(mode), float(r), C.byref(s), _p(idx, _i64_p)),
+                 "mclhip_normalise_resample")
+        return s.value, idx
 
     def step(self, v, omega, dt, alpha, z_meas, r, noise_ints=None, seed=0, weight_mode=W_PRODUCT, wait=True):
         al = _f64(alpha, (6,))

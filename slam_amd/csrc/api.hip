@@ -965,6 +965,20 @@ int mclhip_resample(mclhip_ctx* c, double r, int algo, int64_t* idx_out) {
   return MCLHIP_OK;
 }
 
+int mclhip_normalise_resample(mclhip_ctx* c, int mode, double r, double* sum_out, int64_t* idx_out) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, false, false, true));
+  if (mode != MCLHIP_W_PRODUCT && mode != MCLHIP_W_LOG) return fail(c, MCLHIP_E_ARG, "bad weight mode");
+  span_begin(c, c->spans, 2);
+  MCL_TRY(launch_normalise_resample(c, mode, r));
+  span_end(c, c->spans);
+  MCL_HIP(c, hipStreamSynchronize(c->stream));
+  span_collect(c, c->spans);
+  if (sum_out) MCL_HIP(c, hipMemcpy(sum_out, c->scal, sizeof(double), hipMemcpyDeviceToHost));
+  if (idx_out) MCL_HIP(c, hipMemcpy(idx_out, c->idx, c->M * sizeof(int64_t), hipMemcpyDeviceToHost));
+  return MCLHIP_OK;
+}
+
 static int step_common(mclhip_ctx* c, double v, double omega, double dt, const double alpha[6],
                        const int16_t* noise_ints, uint64_t seed, const double* z_meas, int weight_mode, double r,
                        bool wait) {

@@ -729,11 +729,28 @@ __global__ __launch_bounds__(kScanBlock) void records_kernel(double* __restrict_
   // The block that finishes last walks the irregular records (the serial step of the method).  Hand-over between
   // blocks: every wave waits until its stores have left, the block meets, one lane counts the block in; the block
   // whose count comes last reads what the others stored, with loads that go past the compute unit's own cache.
+  //
+  // Why relaxed atomics and a wait are enough here (and an agent-scope release / acquire pair is not needed).  The
+  // eight XCDs of the GPU have an L2 each; a plain store may stay dirty in the writing XCD's L2, and a release fence at
+  // agent scope writes ALL of that L2's dirty lines back -- this kernel has just written 12 bytes per particle that
+  // nobody shares.  But everything one block hands to another -- the records, their number, the counter -- is written
+  // and read with agent-scope ATOMIC accesses, which are performed at the point all XCDs share (stores write through,
+  // loads bypass lines the local L2 does not own); a store is acknowledged, and counted off vmcnt, only once it has been
+  // performed there.  So: records stored (agent-scope atomic stores) -> s_waitcnt vmcnt(0) in every wave: performed ->
+  // barrier: every wave of the block is past its wait -> one atomic increment, itself totally ordered with the other
+  // blocks' increments at the same point.  The block that reads grid - 1 therefore counts after every other block's
+  // records were performed, and its agent-scope atomic loads read them where they were performed.  The formal pair
+  // (MCL_TAIL_RELACQ: the increment with acquire-release semantics at agent scope) gives the same indices and costs the
+  // write-back and invalidation of an L2 per block: measured slower, see the design notes.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
+#ifdef MCL_TAIL_RELACQ
+    const unsigned int before = __hip_atomic_fetch_add(done_counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+#else
     const unsigned int before = __hip_atomic_fetch_add(done_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     s_last = before == gridDim.x - 1;
   }
   __syncthreads();

@@ -165,6 +165,10 @@ def test_resample_only_cases_and_large():
             idx = ctx.resample(float(g["c%d_r" % c]), algo)
             assert np.array_equal(idx, g["c%d_idx" % c]), (c, algo)
             assert np.array_equal(ctx.get_particles()[1], g["c%d_w_out" % c])
+        ctx.set_particles(np.zeros((len(w), 3)), w)
+        _, idx = ctx.normalise_resample(float(g["c%d_r" % c]), 0)
+        assert np.array_equal(idx, g["c%d_idx" % c]), (c, "fused")
+        assert np.array_equal(ctx.get_particles()[1], g["c%d_w_out" % c])
     # sizes of the benchmark and weight shapes that stress the order-exact scan
     rng = np.random.RandomState(5)
     for M, kind in [(1 << 20, "rand"), (1 << 20, "peaky"), ((1 << 20) + 12345, "zeros"), (300001, "ties"),
@@ -191,6 +195,13 @@ def test_resample_only_cases_and_large():
         idx = ctx.resample(r, 1)
         ref = O.resample_indices(w / np.sum(w), r, clamp=True)
         assert np.array_equal(idx, ref), (M, kind, int(np.sum(idx != ref)))
+        w_out = ctx.get_particles(False, True, False)[1]
+        # the same through the fused update's tail (six kernels; the block that finishes last replays the irregular
+        # records of every block -- thousands of them for these shapes, from all over the grid)
+        ctx.set_particles(np.zeros((M, 3)), w)
+        total_f, idx_f = ctx.normalise_resample(r, 0)
+        assert total_f == total and np.array_equal(idx_f, ref), (M, kind, int(np.sum(idx_f != ref)))
+        assert np.array_equal(ctx.get_particles(False, True, False)[1], w_out)
     # all-zero weights: NaN after normalisation, every index 0
     ctx.set_particles(np.zeros((1000, 3)), np.zeros(1000))
     ctx.normalise(0)
