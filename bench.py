@@ -176,29 +176,51 @@ def stream_copy_ceiling(torch):
     return 2.0 * n * 4 / (ms * 1e-3) / 1e9
 
 
-def profiled_mix(args):
-    """What the committed counter passes say about one launch of the sector-query kernel on the default workload
-    (profiles/rNN_valu_roofline.json, written by tools/valu_roofline.py from rocprofv3 --pmc passes): vector
-    wave-instructions priced with their measured issue cost, the hardware's own count of VALU-active cycles, and the
-    HBM bytes (FETCH_SIZE doubled, as gfx950 tallies 128-byte requests at 64 bytes, + WRITE_SIZE; separate passes).
-    Only valid for the workload the passes were run on; None otherwise."""
+def profiled_mix(args, kernel_name):
+    """What the committed counter passes say about one launch of the sector-query kernel (profiles/rNN_valu_roofline*.json,
+    written by tools/valu_roofline.py from rocprofv3 --pmc passes): vector wave-instructions priced with their measured
+    issue cost, the hardware's own count of VALU-active cycles, and the HBM bytes (FETCH_SIZE doubled, as gfx950 tallies
+    128-byte requests at 64 bytes, + WRITE_SIZE; separate passes).  A profile is quoted only for the workload its passes
+    were run on, and only while it describes the code in the tree: it carries the sha256 of the kernel's source files and
+    the name of the kernel, and one whose sources have changed since, or that is of another instantiation than the run
+    just timed, comes back with `stale` set -- the caller then reports no fraction.  None: no profile of this workload."""
     import glob
-    if (args.particles, args.beams, args.map, args.dtype, args.regime) != (1 << 20, 180, 4096, "f32", "global"):
+    import hashlib
+    want = {"particles": args.particles, "beams": args.beams, "map": args.map, "dtype": args.dtype, "regime": args.regime}
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_roofline*.json"))):
+        d = json.load(open(f))
+        wl = d.get("workload")
+        if wl is None and "grid" not in f:     # profiles of earlier rounds: the default workload, no stamps
+            wl = {"particles": 1 << 20, "beams": 180, "map": 4096, "dtype": "f32", "regime": "global"}
+        if wl == want:
+            best = (f, d)
+    if best is None:
         return None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_roofline.json")))
-    if not files:
-        return None
-    d = json.load(open(files[-1]))
-    d["file"] = os.path.relpath(files[-1], ROOT)
+    f, d = best
+    d["file"] = os.path.relpath(f, ROOT)
+    why = []
+    stamps = d.get("source_sha256")
+    if not stamps:
+        why.append("the profile carries no source stamps")
+    else:
+        for rel, sha in stamps.items():
+            path = os.path.join(ROOT, rel)
+            if not os.path.exists(path) or hashlib.sha256(open(path, "rb").read()).hexdigest() != sha:
+                why.append("%s has changed since the profile was taken" % rel)
+    prof_kernel = d.get("kernel", "").replace("void mcl::", "").replace(" ", "").split("(")[0]
+    if kernel_name and prof_kernel != kernel_name.replace(" ", ""):
+        why.append("the profile is of %s, the run was %s" % (prof_kernel, kernel_name))
+    d["stale"] = why
     return d
 
 
-def roofline(args, M, B, ray_ms, n_ray, copy_gbs):
+def roofline(args, M, B, ray_ms, n_ray, copy_gbs, kernel_name=""):
     """The sector-query kernel against the ceiling that binds it.  It is bound by vector-instruction issue: per
     particle it issues several hundred vector instructions and reads about 1.5 KB, so the figure a launch is held to
     is (vector wave-instructions x issue cycles each) / (SIMDs x clock), with the kernel time measured live; the
     measured HBM rate stands beside it."""
-    mix = profiled_mix(args)
+    mix = profiled_mix(args, kernel_name)
     peak = SIMDS * PEAK_CLOCK_GHZ                       # G SIMD issue cycles per second
     out = {"bound": "valu", "achieved": None, "peak": peak, "unit": "G SIMD issue-cycles/s", "frac": None, "traffic": None,
            "kernel": "raycast_kernel (sector query + beam likelihood; where the query runs as two launches, the first: "
@@ -207,7 +229,12 @@ def roofline(args, M, B, ray_ms, n_ray, copy_gbs):
            "peak_is": "%d SIMD-32 x %.1f GHz" % (SIMDS, PEAK_CLOCK_GHZ),
            "algorithmic_bytes_per_eval": ALGO_BYTES_PER_EVAL,
            "algorithmic_bytes_per_launch": ALGO_BYTES_PER_EVAL * float(M) * B,
-           "stream_copy_GBps": copy_gbs}
+           "stream_copy_GBps": copy_gbs, "kernel_instantiation": kernel_name}
+    if mix and mix["stale"]:
+        out["stale"] = True
+        out["stale_because"] = mix["stale"]
+        out["source"] = mix["file"]
+        return out
     if mix and n_ray:
         sec = ray_ms * 1e-3
         cyc = mix["priced_issue_cycles_per_launch"]
@@ -227,6 +254,22 @@ def roofline(args, M, B, ray_ms, n_ray, copy_gbs):
             out["hbm"] = {"achieved_GBps": gbs, "peak_GBps": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
                           "l2_hit_rate": mix.get("l2_hit_rate")}
         out["source"] = mix["file"]
+        out["stale"] = False
+        if mix.get("lane_utilisation_hw") is not None:
+            out["lane_utilisation_hw"] = mix["lane_utilisation_hw"]
+        if mix.get("cell_loop"):
+            out["lane_utilisation_of_the_cell_loop"] = mix["cell_loop"].get("lane_utilisation_of_the_cell_loop")
+        if mix.get("algorithmic_floor"):
+            af = mix["algorithmic_floor"]
+            out["algorithmic_floor_ms"] = af["floor_ms_at_peak_clock"]
+            out["frac_of_algorithmic_floor"] = af["floor_ms_at_peak_clock"] / ray_ms
+            out["algorithmic_floor_is"] = ("fewest vector wave-instructions per particle with every lane doing needed work "
+                                           "(%d + %d x cells within z_max / 64 + %d x beams / 64 = %.0f against %.0f issued), at the "
+                                           "kernel's average issue cost" % (af["lane_instructions"]["per_particle"],
+                                                                            af["lane_instructions"]["per_cell_in_range"],
+                                                                            af["lane_instructions"]["per_beam"],
+                                                                            af["wave_instructions_per_particle"],
+                                                                            af["wave_instructions_per_particle_issued"]))
     return out
 
 
@@ -238,12 +281,36 @@ def dry_run(a, rank, world, json_fd):
     t = torch.ones(1, dtype=torch.int64)
     dist.all_reduce(t)
     dist.barrier()
+    # what the real run would set up, checked without a GPU: the layout of the global particle vector over the ranks
+    # (every rank but the last holds whole 8192-element chunks: the sum is formed chunk by chunk in rank order), and the
+    # device memory one rank's particle state takes
+    M = a.particles
+    problems = []
+    if M % 8192 and world > 1:
+        problems.append("particles per GPU must be a multiple of 8192 on every rank but the last")
+    if M > (1 << 31):
+        problems.append("at most 2^31 particles per context")
+    if a.beams > 1024:
+        problems.append("at most 1024 beams")
+    if a.map > 65535:
+        problems.append("map sides are limited to 65535 cells")
+    state = 4 if a.dtype == "f32" else 8
+    per_particle = 2 * (3 * state + 8) + 8 + 1 + 8 * 3 + 8 + 4 + 24 + 24 + 8 + 4 + (32 if a.dtype == "f32" else 0)
     if rank == 0:
         line = json.dumps({"metric": "particle-beam evals/sec (node) + ms per MCL step, 1M particles x 180 beams",
                            "value": None, "unit": "particle-beam evals/s", "n_gpus": world, "dry_run": True,
-                           "world_size_seen": int(t.item()), "steps": a.steps, "warmup": a.warmup})
+                           "world_size_seen": int(t.item()), "steps": a.steps, "warmup": a.warmup,
+                           "plan": {"particles_total": M * world, "particles_per_gpu": M, "beams": a.beams, "map": a.map,
+                                    "first_index_per_rank": [r * M for r in range(world)],
+                                    "chunks_of_8192_per_rank": (M + 8191) // 8192,
+                                    "fused_tail": (M + 8191) // 8192 <= 1024,
+                                    "particle_state_bytes_per_gpu": per_particle * M,
+                                    "evaluations_per_step": float(M) * world * a.beams,
+                                    "problems": problems}})
         os.write(json_fd, (line + "\n").encode())
     dist.destroy_process_group()
+    if problems:
+        sys.exit(2)
 
 
 def main():
@@ -291,8 +358,9 @@ def main():
     w4 = np.array([0.97, 0.005, 0.020, 0.005])
     w4 = w4 / w4.sum()
     ctx.set_sensor(angles, W.Z_MAX, 0.15, 1.0, w4, 5 * np.pi / 180.0)
-    X_all = W.uniform_particles(grid, M * world)           # identical on every rank
-    X = X_all[rank * M:(rank + 1) * M]
+    # The global cloud is the ranks' slices one after the other; every rank draws only its own (seeded by its rank:
+    # rank 0's slice is the one-GPU cloud), not the whole set -- 2^26 poses at configs[2] -- to keep one eighth of it.
+    X = W.uniform_particles(grid, M, seed=W.SEED_PARTICLES + 7919 * rank)
     ctx.set_particles(X)
     ctx.snapshot_particles()
 
@@ -300,7 +368,11 @@ def main():
     n_total = a.warmup + a.steps
     ctrl = W.controls(n_total)
     from slam_amd.mc_localization import advance_true_pose
-    x_gt = X_all[0].copy()
+    x_gt = X[0].copy()                                      # the true pose starts as particle 0 of rank 0
+    if dist is not None and world > 1:
+        t_gt = torch.from_numpy(x_gt).to("cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.broadcast(t_gt, 0)
+        x_gt = t_gt.cpu().numpy().copy()
     z_meas = []
     for (v, om) in ctrl:
         x_gt = advance_true_pose(x_gt, (v, om), 0.1)
@@ -339,7 +411,18 @@ def main():
         te = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
+    # rows of the exchange: the largest per-rank figures (the slowest rank sets the step time)
+    ex_rows = getattr(filt, "rows_sent_total", 0) / max(getattr(filt, "steps_done", 0), 1)
+    ex_off = getattr(filt, "rows_sent_off_rank", 0) / max(getattr(filt, "steps_done", 0), 1)
+    if dist is not None and world > 1:
+        te = torch.tensor([ex_rows, ex_off], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        ex_rows, ex_off = float(te[0].item()), float(te[1].item())
     n_ray, ms_ray = ctx.timing_get(0)
+    try:
+        kernel_name = ctx.query_kernel_name()
+    except AttributeError:                   # a library build without the name
+        kernel_name = ""
     # the other kernel groups, for the record: a few more steps outside the timed region with every group timed
     ctx.timing_enable(True)
     for t in range(a.warmup, min(a.warmup + 5, n_total)):
@@ -378,10 +461,9 @@ def main():
                        "sharding": ("contiguous particle ranges, map replicated; %s" %
                                     ("device-driven exchange" if filt.device_path else "host-combined exchange"))
                        if filt.collective else "single GPU"},
-            "roofline": roofline(a, M, B, ray_ms, n_ray, copy_gbs),
-            "exchange": ({"rows_per_step_this_rank": getattr(filt, "rows_sent_total", 0) / max(getattr(filt, "steps_done", 0), 1),
-                          "bytes_between_ranks_per_step_this_rank":
-                              48.0 * getattr(filt, "rows_sent_off_rank", 0) / max(getattr(filt, "steps_done", 0), 1),
+            "roofline": roofline(a, M, B, ray_ms, n_ray, copy_gbs, kernel_name),
+            "exchange": ({"rows_per_step_max_over_ranks": ex_rows,
+                          "bytes_between_ranks_per_step_max_over_ranks": 48.0 * ex_off,
                           "host_reads_per_step": 1 if filt.device_path else "host-combined: about 13",
                           "note": "only rows that some position draws travel (48 B each)"}
                          if filt.collective else None),

@@ -486,6 +486,11 @@ int mclhip_fs_dshard_unpack(mclhip_ctx* ctx, const void* d_rows, const void* d_f
  * on: 0 off, 1 every group, 2 the sector-query kernel only (two events per step instead of six: an event between
  * two kernels costs a few microseconds of idle GPU).  Enabling resets the accumulators. */
 int mclhip_timing_enable(mclhip_ctx* ctx, int on);
+/* Name of the sector-query kernel instantiation the last query of this context ran (where it ran as two launches: the
+ * first), as a profiler prints it with the blanks left out -- "raycast_kernel<float,false,...>"; "" before the
+ * first query.  Measurement only: lets a benchmark tie its figures to the profile of the very kernel it timed.  No
+ * counterpart in the reference.  The string belongs to the context and is valid until its next query. */
+const char* mclhip_query_kernel_name(mclhip_ctx* ctx);
 int mclhip_timing_get(mclhip_ctx* ctx, int which, int64_t* launches, double* total_ms);
 
 #ifdef __cplusplus

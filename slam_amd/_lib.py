@@ -121,6 +121,7 @@ PROTOTYPES = {
     "mclhip_shard_unpack_drawn": (C.c_int, [_ctx_p, C.c_void_p, C.c_int64, C.c_double, _i64_p]),
     "mclhip_timing_enable": (C.c_int, [_ctx_p, C.c_int]),
     "mclhip_timing_get": (C.c_int, [_ctx_p, C.c_int, _i64_p, _dbl_p]),
+    "mclhip_query_kernel_name": (C.c_char_p, [_ctx_p]),
 }
 
 
@@ -684,6 +685,10 @@ class Context:
     def timing_enable(self, on=True):
         """on: False / True (every kernel group) / 2 (the sector-query kernel only)."""
         self._ck(self.lib.mclhip_timing_enable(self.h, 2 if on == 2 else (1 if on else 0)), "mclhip_timing_enable")
+
+    def query_kernel_name(self):
+        """The sector-query instantiation the last query ran, e.g. 'raycast_kernel<float,false,...>'."""
+        return (self.lib.mclhip_query_kernel_name(self.h) or b"").decode()
 
     def timing_get(self, which):
         n = C.c_int64(0)

@@ -1407,6 +1407,8 @@ int mclhip_shard_unpack_drawn(mclhip_ctx* c, const void* rows, int64_t L, double
   return MCLHIP_OK;
 }
 
+const char* mclhip_query_kernel_name(mclhip_ctx* c) { return c ? c->query_kernel.c_str() : ""; }
+
 int mclhip_timing_enable(mclhip_ctx* c, int on) {
   if (!c) return MCLHIP_E_ARG;
   c->timing = on == 2 ? 2 : (on != 0 ? 1 : 0);

@@ -203,6 +203,7 @@ struct mclhip_ctx {
   // a hint, a step old): when most of the cloud is left over (headings outside the interval path's range) the query
   // runs as one kernel, which serves such a cloud faster than two launches do, and probes again every eighth query.
   uint32_t* redo_hint = nullptr;
+  std::string query_kernel;     // the sector-query instantiation the last query ran (its first launch, if it ran as two)
   int split_mode = -1;          // -1 by the hint, 0 never two launches, 1 always (environment MCLHIP_SPLIT at creation)
   int64_t split_skipped = 0;
   void* px[2] = {nullptr, nullptr};

@@ -1215,6 +1215,15 @@ int launch_grid_update(mclhip_ctx* c, const double* d_x, const double* d_y, cons
   return MCLHIP_OK;
 }
 
+// the instantiation's name as the profiler prints it, blanks left out
+static std::string ray_kernel_name(bool f32, bool stage, bool product, bool grid, int wpb, bool rnoise, bool fast, bool ivonly,
+                                   bool listed, int cap, int unif) {
+  auto b = [](bool v) { return v ? "true" : "false"; };
+  return std::string("raycast_kernel<") + (f32 ? "float" : "double") + "," + b(stage) + "," + b(product) + "," + b(grid) + "," +
+         std::to_string(wpb) + "," + b(rnoise) + "," + b(fast) + "," + b(ivonly) + "," + b(listed) + "," + std::to_string(cap) + "," +
+         std::to_string(unif) + ">";
+}
+
 int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, const uint8_t* pm, int64_t n,
                    int dtype, double* w_out, double* logw_out, double* ranges_out, int32_t* hits_out,
                    const double* range_noise, double rn_sigma, uint64_t rn_seed, const QueryRecord* qrec) {
@@ -1270,6 +1279,7 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
 #define MCL_RAY_U(TT, SS, PP, NN, FF, WW, II, LL, CC, UU)                                                              \
   do {                                                                                                               \
     auto kern = raycast_kernel<TT, SS, PP, false, WW, NN, FF, II, LL, CC, UU>;                                         \
+    if (!(LL)) c->query_kernel = ray_kernel_name(sizeof(TT) == 4, SS, PP, false, WW, NN, FF, II, LL, CC, UU);        \
     if (lds > 48 * 1024)                                                                                             \
       MCL_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                      (int)lds));                                                                     \

@@ -26,6 +26,26 @@ def test_launcher_starts_two_ranks_without_a_gpu():
     assert d["n_gpus"] == 2 and d["world_size_seen"] == 2 and d["dry_run"] is True
 
 
+def test_dry_run_of_the_eight_gpu_configuration():
+    """The line BASELINE.json's configs[2] is run with -- 64M particles x 360 beams on the 16384^2 grid over eight
+    GPUs -- through the launcher and the rendezvous, without a GPU: eight ranks, the layout of the global particle
+    vector, no limit of the library exceeded."""
+    rc, out, err = _run(["--gpus", "8", "--particles", "8388608", "--beams", "360", "--map", "16384", "--dry-run"], timeout=600)
+    assert rc == 0, err[-2000:]
+    d = json.loads([x for x in out.splitlines() if x.strip()][0])
+    assert d["n_gpus"] == 8 and d["world_size_seen"] == 8
+    plan = d["plan"]
+    assert plan["particles_total"] == 1 << 26 and plan["problems"] == []
+    assert plan["first_index_per_rank"][7] == 7 * (1 << 23) and plan["chunks_of_8192_per_rank"] == 1024 and plan["fused_tail"]
+    assert plan["particle_state_bytes_per_gpu"] < 4 << 30
+    assert plan["evaluations_per_step"] == float(1 << 26) * 360
+    # a layout the library refuses is reported before anything is launched on a GPU
+    rc, out, err = _run(["--gpus", "2", "--particles", "100000", "--dry-run"])
+    assert rc != 0
+    d = json.loads([x for x in out.splitlines() if x.strip()][0])
+    assert "8192" in d["plan"]["problems"][0]
+
+
 def test_launcher_refuses_more_ranks_than_gpus():
     """The launcher counts GPUs from the driver's topology files (no torch, no HIP in the parent) and refuses at once;
     where there is no topology to read (a box without the driver) the ranks fail by themselves and it reports that."""

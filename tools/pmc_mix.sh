@@ -18,4 +18,6 @@ run grbm GRBM_GUI_ACTIVE GRBM_COUNT
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run l2 TCC_HIT_sum TCC_MISS_sum
+# lanes switched on per vector instruction (a build of the profiler that does not know the counter fails this pass only)
+timeout -s KILL 150 rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VALU --output-format csv -d $out/pmc_lanes -o p -- python $script > $out/pmc_lanes.log 2>&1 || echo "pass lanes failed (skipped)"
 echo passes done

@@ -40,3 +40,16 @@ cn = ["batches (wave)", "match calls (wave)", "cells within z_max (lane)", "wind
 c = np.array([ctx.timing_get(108 + i)[0] for i in range(8)], float) - np.array(base8, float)
 for n, v in zip(cn, c):
     print("%-34s %10.3f per particle" % (n, v / M))
+if os.environ.get("MCL_COUNTS_JSON") and not GRID_MODE:
+    # (counting build) what the cell loop of the interval-only kernel fetched and what of it was within z_max
+    import json
+    from scipy.spatial import cKDTree
+    oi, oj = np.nonzero(grid == 0)
+    tree = cKDTree(np.stack([oj * np.float32(W.RES), oi * np.float32(W.RES)], 1).astype(np.float64))
+    cells = float(np.mean(tree.query_ball_point(X[:8192, :2], W.Z_MAX, return_length=True)))
+    batches = float(c[0]) / M
+    json.dump({"batches_of_64_per_particle": batches, "lane_slots_fetched_per_particle": 64.0 * batches,
+               "cells_within_z_max_per_particle": cells,
+               "lane_utilisation_of_the_cell_loop": cells / (64.0 * batches),
+               "note": "counting build (make -C slam_amd/csrc counts), one step of the benchmark workload; both launches of the query"},
+              open(os.environ["MCL_COUNTS_JSON"], "w"), indent=1)

@@ -15,10 +15,34 @@ It also reports the hardware's own figure, SQ_ACTIVE_INST_VALU (in quad-cycles),
 reproduce.
 
     python tools/valu_roofline.py <pmc_summary.json> <issue_cost.json> <kernel.s> <symbol-substring> <out.json> [<name-in-counters>]
+        [--sources file ...] [--workload JSON] [--work particles,cells_in_range,beams] [--counts counts.json]
+
+--sources: the files the kernel is built from; their sha256 goes into the output, and bench.py refuses to quote a
+profile whose sources are not the ones in the tree (`stale`).  --workload: what the counter passes were run on
+(bench.py quotes a profile only for that workload).  --work: sizes for the ALGORITHMIC floor, below.
+
+Two figures beside the issue fraction say how much of the issued work is needed at all:
+  * lane utilisation: of the 64 lanes of a vector instruction, how many were switched on, on average
+    (SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU x 4), when the pass has the counter; and from the counting
+    build of the kernel: obstacle cells within z_max per fetched lane-slot of the cell loop);
+  * the algorithmic instruction floor: the fewest vector wave-instructions a particle needs on this hardware if
+    every lane of every instruction did needed work --
+        ALGO_PER_PARTICLE + ALGO_PER_CELL x cells_in_range / 64 + ALGO_PER_BEAM x beams / 64
+    (the constants are counted out instruction by instruction in the design notes) -- priced with the kernel's
+    average issue cost; `frac_of_algorithmic_floor` = that time / the measured kernel time.
 """
+import hashlib
 import json
+import os
 import re
 import sys
+
+# fewest vector instructions (per lane that does needed work): see the design notes, sector query
+ALGO_PER_CELL = 41       # unpack + float32 coordinates and differences 4, exact float64 squared distance 6, range test 1,
+                         # float32 bearing 20, place on the circle of intervals and distance to its edges 9, LDS address 1
+ALGO_PER_BEAM = 30       # four float64 minima over the five intervals of a sector, root, the float32 mixture with two
+                         # exponentials, the float64 product
+ALGO_PER_PARTICLE = 50   # record (7 lane reads), clearing the minima, one logarithm of the lane's product, the exact lane sum, the result
 
 SIMDS = 1024          # 256 CUs x 4 SIMD-32
 CLOCK_GHZ = 2.4       # maximum shader clock
@@ -94,9 +118,28 @@ def static_mix(asm_path, kernel_sub, table):
     return m.group(1), mix
 
 
+def options(argv):
+    """positional arguments, and the --name value ... options as a dict of lists"""
+    pos, opt, cur = [], {}, None
+    for a in argv:
+        if a.startswith("--"):
+            cur = a[2:]
+            opt[cur] = []
+        elif cur is None:
+            pos.append(a)
+        else:
+            opt[cur].append(a)
+    return pos, opt
+
+
+def sha256_of(path):
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()
+
+
 def main():
-    pmc, cost, asm, ksub, out = sys.argv[1:6]
-    pmc_name = sys.argv[6] if len(sys.argv) > 6 else "raycast_kernel<float, false, false, false"
+    pos, opt = options(sys.argv[1:])
+    pmc, cost, asm, ksub, out = pos[:5]
+    pmc_name = pos[5] if len(pos) > 5 else "raycast_kernel<float, false, false, false"
     table = {k: v["cycles"] for k, v in json.load(open(cost))["cycles_per_wave64_instruction_per_simd"].items()}
     kname, mix = static_mix(asm, ksub, table)
     ctr = None
@@ -141,6 +184,29 @@ def main():
                 "INT32 and OTHER (moves, selects, float compares, lane operations) are priced with the static opcode mix of the "
                 "kernel's code; SQ_ACTIVE_INST_VALU counts quad-cycles",
     }
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if "sources" in opt:
+        res["source_sha256"] = {os.path.relpath(os.path.abspath(f), root): sha256_of(f) for f in opt["sources"]}
+    if "workload" in opt:
+        res["workload"] = json.loads(" ".join(opt["workload"]))
+    # lane utilisation by the hardware's count, when the passes have it
+    if ctr.get("SQ_THREAD_CYCLES_VALU") and ctr.get("SQ_ACTIVE_INST_VALU"):
+        res["lane_utilisation_hw"] = ctr["SQ_THREAD_CYCLES_VALU"] / (64.0 * 4.0 * ctr["SQ_ACTIVE_INST_VALU"])
+        res["lane_utilisation_hw_is"] = "SQ_THREAD_CYCLES_VALU / (64 x 4 x SQ_ACTIVE_INST_VALU): lanes switched on per vector instruction"
+    if "counts" in opt:
+        res["cell_loop"] = json.load(open(opt["counts"][0]))
+    if "work" in opt:
+        particles, cells, beams = [float(x) for x in opt["work"][0].split(",")]
+        per_particle = ALGO_PER_PARTICLE + ALGO_PER_CELL * cells / 64.0 + ALGO_PER_BEAM * beams / 64.0
+        cpi = priced / total
+        res["algorithmic_floor"] = {
+            "particles": particles, "cells_in_range": cells, "beams": beams,
+            "lane_instructions": {"per_cell_in_range": ALGO_PER_CELL, "per_beam": ALGO_PER_BEAM, "per_particle": ALGO_PER_PARTICLE},
+            "wave_instructions_per_particle": per_particle,
+            "wave_instructions_per_particle_issued": total / particles,
+            "issue_cycles_per_instruction": cpi,
+            "floor_ms_at_peak_clock": per_particle * particles * cpi / SIMDS / (CLOCK_GHZ * 1e9) * 1e3,
+            "is": "every lane of every vector instruction doing needed work: no cell outside z_max fetched, no half-empty batch"}
     json.dump(res, open(out, "w"), indent=1)
     print("VALU wave-instructions per launch  %.4g" % total)
     for b in dyn:
