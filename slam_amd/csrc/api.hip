@@ -2,6 +2,7 @@
 // <-> device staging and the order in which the stage kernels are enqueued.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -142,16 +143,31 @@ int build_ring_table(mclhip_ctx* c) {
   (void)hipFree(d_cnt);
   if (rc != MCLHIP_OK) return rc;
   if (e != hipSuccess) return fail(c, MCLHIP_E_HIP, std::string("neighbourhood count: ") + hipGetErrorString(e));
-  std::vector<uint32_t> off(ne + 1);
+  std::vector<uint64_t> off(ne + 1);
   uint64_t acc = 0;
-  for (size_t t = 0; t < ne; ++t) { off[t] = (uint32_t)acc; acc += (cnt[t] + 63u) & ~63ull; }   // whole batches of 64: the fill pads them
-  if (acc > 0xffffffffull) return fail(c, MCLHIP_E_LIMIT, "neighbourhood lists exceed 2^32 entries (map too large for this z_max)");
-  off[ne] = (uint32_t)acc;
+  for (size_t t = 0; t < ne; ++t) { off[t] = acc; acc += (cnt[t] + 63u) & ~63ull; }   // whole batches of 64: the fill pads them
+  off[ne] = acc;
   if (c->nbr_off) { (void)hipFree(c->nbr_off); c->nbr_off = nullptr; }
   if (c->nbr_cells) { (void)hipFree(c->nbr_cells); c->nbr_cells = nullptr; }
-  MCL_HIP(c, hipMalloc((void**)&c->nbr_off, (ne + 1) * sizeof(uint32_t)));
-  MCL_HIP(c, hipMalloc((void**)&c->nbr_cells, (acc ? acc : 1) * sizeof(uint32_t)));
-  MCL_HIP(c, hipMemcpy(c->nbr_off, off.data(), (ne + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+  // The lists are what the map costs in device memory: four bytes per entry, offsets of eight per query tile.  They
+  // are refused, before anything is allocated, when they would not fit what the device has free (less a tenth: the
+  // particles come later) -- or MCLHIP_LIST_BUDGET_GB, if the environment sets one.
+  {
+    const double need = (double)acc * sizeof(uint32_t) + (double)(ne + 1) * sizeof(uint64_t);
+    size_t free_b = 0, total_b = 0;
+    double budget = 0.0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = 0.9 * (double)free_b;
+    if (const char* e = std::getenv("MCLHIP_LIST_BUDGET_GB")) { const double v = std::atof(e) * 1e9; if (v > 0.0 && (budget == 0.0 || v < budget)) budget = v; }
+    if (budget > 0.0 && need > budget) {
+      char msg[256];
+      std::snprintf(msg, sizeof(msg), "neighbourhood lists of this map need %.1f GB of device memory (%.3g entries), %.1f GB are available: "
+                    "a coarser map, a smaller z_max or fewer obstacle cells", need / 1e9, (double)acc, budget / 1e9);
+      return fail(c, MCLHIP_E_LIMIT, msg);
+    }
+  }
+  MCL_HIP(c, hipMalloc((void**)&c->nbr_off, (ne + 1) * sizeof(uint64_t)));
+  MCL_HIP(c, hipMalloc((void**)&c->nbr_cells, (size_t)(acc ? acc : 1) * sizeof(uint32_t)));
+  MCL_HIP(c, hipMemcpy(c->nbr_off, off.data(), (ne + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
   rc = launch_nbr_fill(c);
   if (rc != MCLHIP_OK) return rc;
   MCL_HIP(c, hipStreamSynchronize(c->stream));

@@ -85,7 +85,7 @@ __device__ inline bool cell_in_reach(const NbrGeom& g, int qrow0, int qcol0, uin
 template <bool FILL>
 __global__ __launch_bounds__(256) void nbr_list_kernel(const uint32_t* __restrict__ tile_off,
                                                        const uint32_t* __restrict__ cells, const uint16_t* __restrict__ ring,
-                                                       NbrGeom g, const uint32_t* __restrict__ nbr_off,
+                                                       NbrGeom g, const uint64_t* __restrict__ nbr_off,
                                                        uint32_t* __restrict__ out_buf) {
   const int SW = g.ETW << kQueryShift, SH = g.ETH << kQueryShift;
   const int lane = threadIdx.x & 63;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void nbr_list_kernel(const uint32_t* __restric
   const int ty = (sy >> kQueryShift) - g.rty, tx = (sx >> kQueryShift) - g.rtx;   // the 8x8 tile it lies in
   const int qrow0 = ty * 8 + (sy & ((1 << kQueryShift) - 1)) * kQueryCells;
   const int qcol0 = tx * 8 + (sx & ((1 << kQueryShift) - 1)) * kQueryCells;
-  uint32_t out = FILL ? nbr_off[t] : 0u;
+  uint64_t out = FILL ? nbr_off[t] : 0ull;   // (FILL: place in the lists; else: the count, which fits 32 bits)
   for (int r = 0; r < g.n_ring; ++r) {
     const int y = ty + (int)(ring[r] >> 8) - 128, x = tx + (int)(ring[r] & 0xffu) - 128;
     if (y < 0 || y >= g.TH || x < 0 || x >= g.TW) continue;
@@ -112,12 +112,12 @@ __global__ __launch_bounds__(256) void nbr_list_kernel(const uint32_t* __restric
     }
     out += (uint32_t)__popcll(km);
   }
-  if (!FILL && lane == 0) out_buf[t] = out;
+  if (!FILL && lane == 0) out_buf[t] = (uint32_t)out;
   if (FILL) {
     // A list occupies whole batches of 64 entries; the rest of the last batch is a cell no pose of the query tile can
     // reach (the far end of the column range: reach is at most 127 tiles), so that a walk needs no per-lane bounds.
     const uint32_t pad = qcol0 < 32768 ? 0xffffu : 0u;   // row 0, last or first column
-    for (uint32_t i = out + (uint32_t)lane; i < nbr_off[t + 1]; i += 64u) out_buf[i] = pad;
+    for (uint64_t i = out + (uint64_t)lane; i < nbr_off[t + 1]; i += 64u) out_buf[i] = pad;
   }
 }
 
@@ -135,7 +135,7 @@ static NbrGeom nbr_geom(const mclhip_ctx* c) {
 int launch_nbr_count(mclhip_ctx* c, uint32_t* d_cnt) {
   const int64_t ne = ((int64_t)c->ETW << kQueryShift) * ((int64_t)c->ETH << kQueryShift);
   hipLaunchKernelGGL(nbr_list_kernel<false>, dim3((unsigned)((ne + 3) / 4)), dim3(256), 0, c->stream, c->tile_off, c->cells,
-                     c->ring, nbr_geom(c), (const uint32_t*)nullptr, d_cnt);
+                     c->ring, nbr_geom(c), (const uint64_t*)nullptr, d_cnt);
   MCL_HIP(c, hipGetLastError());
   return MCLHIP_OK;
 }
@@ -257,18 +257,18 @@ __global__ __launch_bounds__(256) void motion_kernel(T* __restrict__ xs, T* __re
     const bool served = fabsf(rec.th - q.th_mid) <= q.th_hi;
     const float fxc = rec.x * q.inv_res_xf, fyc = rec.y * q.inv_res_yf;
     const bool pose_ok = (fabsf(fxc) < 1.0e6f) && (fabsf(fyc) < 1.0e6f);   // far outside any map, or NaN: no tile
-    uint32_t first = 0u, n_cells = 0u;
+    uint64_t first = 0ull;
+    uint32_t n_cells = 0u;
     if (pose_ok && served) {
       const int ex = (((int)floorf(fxc)) >> (3 - kQueryShift)) + q.rtx, ey = (((int)floorf(fyc)) >> (3 - kQueryShift)) + q.rty;
       if (ex >= 0 && ex < q.ETW && ey >= 0 && ey < q.ETH) {
-        const uint32_t* no = q.nbr_off + ((size_t)ey * q.ETW + ex);
+        const uint64_t* no = q.nbr_off + ((size_t)ey * q.ETW + ex);
         first = no[0];
-        n_cells = no[1] - first;
+        n_cells = (uint32_t)(no[1] - first);
       }
     }
-    rec.first = first; rec.n_cells = n_cells;
+    rec.first_lo = (uint32_t)first; rec.first_hi = (uint32_t)(first >> 32); rec.n_cells = n_cells;
     rec.flags = (fr ? 1u : 0u) | (served ? 2u : 0u);
-    rec.pad = 0u;
     uint4* dst = reinterpret_cast<uint4*>(&q.out[i]);
     const uint4* src = reinterpret_cast<const uint4*>(&rec);
     dst[0] = src[0];

@@ -33,7 +33,8 @@ constexpr int kQueryCells = 8 >> kQueryShift;
 
 // Everything the sector-query kernel needs about the map and the sensor.
 struct RayParams {
-  const uint32_t* nbr_off;   // [ETH*ETW + 1] start of each query tile's neighbourhood list in nbr_cells[]
+  const uint64_t* nbr_off;   // [ETH*ETW + 1] start of each query tile's neighbourhood list in nbr_cells[] (64-bit: a
+                             // 16384^2 map with a fifth of its cells occupied lists 4.6e9 entries)
   const uint32_t* nbr_cells; // per tile: the obstacle cells (row << 16 | col) of every tile that can hold a cell
                              // within z_max of a point of that tile, nearest tile first
   int ETW, ETH, rtx, rty;    // the query-tile grid, extended by rtx / rty query tiles on each side (poses just outside the map)
@@ -115,14 +116,14 @@ struct QueryRecord {
   float x, y, th;        // the pose as stored (float32 state)
   float tho;             // (heading + angle of interval edge 0) in turns: a bearing in turns minus this, its fraction
                          // taken, is the bearing's place on the circle of sector intervals
-  uint32_t first, n_cells;   // the slice of RayParams::nbr_cells the particle has to look at (whole batches of 64)
+  uint32_t first_lo, first_hi;   // the slice of RayParams::nbr_cells the particle has to look at starts here (64 bits) ...
+  uint32_t n_cells;      // ... and is this long (whole batches of 64)
   uint32_t flags;        // bit 0: the pose rounds to a free cell; bit 1: the heading is one the interval path serves
-  uint32_t pad;
 };
 static_assert(sizeof(QueryRecord) == 32, "two 16-byte loads");
 struct QueryPrep {
   QueryRecord* out;      // null: no records are written
-  const uint32_t* nbr_off;
+  const uint64_t* nbr_off;
   int ETW, ETH, rtx, rty;
   float inv_res_xf, inv_res_yf;
   float th_mid, th_hi;   // |heading - th_mid| <= th_hi: served by the interval path (RayParams::iv_th_*)
@@ -159,7 +160,7 @@ struct mclhip_ctx {
   uint64_t* freeb = nullptr;    // free-cell bit plane
   uint32_t* tile_off = nullptr; // per-tile obstacle lists: offsets ...
   uint32_t* cells = nullptr;    // ... and entries
-  uint32_t* nbr_off = nullptr;  // per-tile neighbourhood lists (built from the two above and the ring table)
+  uint64_t* nbr_off = nullptr;  // per-tile neighbourhood lists (built from the two above and the ring table)
   uint32_t* nbr_cells = nullptr;
   int ETW = 0, ETH = 0, rtx = 0, rty = 0;
   int64_t n_obstacles = 0;

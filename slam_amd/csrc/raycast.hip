@@ -318,8 +318,15 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
   if (!STAGE)
     for (int k = threadIdx.x; k < NT; k += blockDim.x) {
       if constexpr (FAST) {
+        // z*^2 -- as the largest float64 whose correctly rounded root does not exceed z*: the short-reading term
+        // applies where sqrt(r2) <= z* (range_sensor.py:47), decided below on r2 itself, and fl(z* z*) can fall an ulp
+        // short of the r2 whose root z* is (a particle that stands where the measurement was taken has z == z* in
+        // every beam).  The difference r2 - z*^2 that the Gaussian term takes from this entry is the same to 2e-16.
         const double zs = P.zt[k];
-        s_zt[k] = zs * zs;                                            // z*^2, float64
+        double c2 = zs * zs;
+        for (int it = 0; it < 4 && sqrt(__longlong_as_double(__double_as_longlong(c2) + 1)) <= zs; ++it) c2 = __longlong_as_double(__double_as_longlong(c2) + 1);
+        for (int it = 0; it < 4 && c2 > 0.0 && sqrt(c2) > zs; ++it) c2 = __longlong_as_double(__double_as_longlong(c2) - 1);
+        s_zt[k] = c2;
         reinterpret_cast<float2*>(s_el)[k] = make_float2((float)zs, (float)(P.etalam[k] * P.w_short));
       } else {
         s_zt[k] = P.zt[k];
@@ -345,7 +352,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
 
   // The map fields arrive as one eight-register load; copied out one by one (opaque to the compiler) they are separate
   // values to the register allocator, which otherwise spills and refills the eight as a block for every use of one.
-  const uint32_t* nbr_off = P.nbr_off;
+  const uint64_t* nbr_off = P.nbr_off;
   const uint32_t* nbr_cells = P.nbr_cells;
   int ETW = P.ETW, ETH = P.ETH, rtx = P.rtx, rty = P.rty;
   if constexpr (!GRID) asm volatile("" : "+s"(nbr_off), "+s"(nbr_cells), "+s"(ETW), "+s"(ETH), "+s"(rtx), "+s"(rty));
@@ -476,7 +483,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
   // +1.5 % in the tracking regime: the kernel does not wait for memory.)
   unsigned int e_pref = 0u;
   if constexpr (IVONLY) {
-    if (have && __builtin_amdgcn_readlane((int)n_rec, 5) != 0) e_pref = P.nbr_cells[(unsigned int)__builtin_amdgcn_readlane((int)n_rec, 4) + lane0];
+    if (have && __builtin_amdgcn_readlane((int)n_rec, 6) != 0)
+      e_pref = P.nbr_cells[((uint64_t)(unsigned int)__builtin_amdgcn_readlane((int)n_rec, 4) | ((uint64_t)(unsigned int)__builtin_amdgcn_readlane((int)n_rec, 5) << 32)) + lane0];
     // (nothing outstanding when the loop is entered: what the compiler must assume at the head of the loop is then what
     // an iteration leaves behind -- the prefetched batch and the result's store -- and it waits where those are used)
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
@@ -493,7 +501,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
     auto rec_word = [&](int k) { return IVONLY ? (unsigned int)__builtin_amdgcn_readlane((int)n_rec, k) : 0u; };
     if constexpr (IVONLY) { nx = (T)__uint_as_float(rec_word(0)); ny = (T)__uint_as_float(rec_word(1)); nth = (T)__uint_as_float(rec_word(2)); }
     const float tho = __uint_as_float(rec_word(3));
-    const unsigned int c_first = rec_word(4), c_ncells = rec_word(5), c_flags = rec_word(6);
+    const uint64_t c_first = (uint64_t)rec_word(4) | ((uint64_t)rec_word(5) << 32);
+    const unsigned int c_ncells = rec_word(6), c_flags = rec_word(7);
     const double x = (double)nx, y = (double)ny, th = (double)nth;
     const bool on_free = IVONLY ? (c_flags & 1u) != 0u : npm != 0;
     // headings for which the reference's predicate is the circular one take the interval path (wave-uniform); a
@@ -511,7 +520,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
     const int tcx = pose_ok ? ((int)floor(fxc)) >> (3 - kQueryShift) : 0;   // query tile
     const int tcy = pose_ok ? ((int)floor(fyc)) >> (3 - kQueryShift) : 0;
     // the particle's slice of neighbourhood cells; NaN / infinite headings match no beam
-    unsigned int first_cell = 0u, n_cells = 0u;
+    uint64_t first_cell = 0ull;
+    unsigned int n_cells = 0u;
     if constexpr (IVONLY) {
       // (the record holds the slice of the particle's tile; no cells for a particle this kernel does not serve)
       first_cell = c_first;
@@ -519,9 +529,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
     } else {
       const int ex = tcx + rtx, ey = tcy + rty;
       if (pose_ok && fabs(th) < INFINITY && ex >= 0 && ex < ETW && ey >= 0 && ey < ETH && (!IVONLY || use_iv)) {
-        const unsigned int* no = nbr_off + ((size_t)ey * ETW + ex);
+        const uint64_t* no = nbr_off + ((size_t)ey * ETW + ex);
         first_cell = no[0];
-        n_cells = no[1] - first_cell;
+        n_cells = (unsigned int)(no[1] - first_cell);
       }
     }
     const float xf = (float)x, yf = (float)y;
@@ -758,7 +768,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
         // prefetch below included -- wherever a register of the cell loop is written again.
         __builtin_amdgcn_s_waitcnt(0x0F70);
         // (the next record has arrived by now)
-        if (have && __builtin_amdgcn_readlane((int)n_rec, 5) != 0) e_pref = P.nbr_cells[(unsigned int)__builtin_amdgcn_readlane((int)n_rec, 4) + lane];
+        if (have && __builtin_amdgcn_readlane((int)n_rec, 6) != 0)
+          e_pref = P.nbr_cells[((uint64_t)(unsigned int)__builtin_amdgcn_readlane((int)n_rec, 4) | ((uint64_t)(unsigned int)__builtin_amdgcn_readlane((int)n_rec, 5) << 32)) + lane];
       }
       for (unsigned int sb = 0; sb < n_cells; sb += 64) {
         const unsigned int e = e_next;
@@ -998,7 +1009,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
     } else if constexpr (FAST) {
       // range_sensor.py:31-112 per beam, float32 (see the comment at the template head).  What is exact:
       //   0 <= z <= z_max holds for every entry (r2 <= z_max^2 by construction), so p_hit and p_rand always apply;
-      //   z <= z*  <=>  r2 <= z*^2 (float64);  |z - z_max| < 1e-6  <=>  r2 > (z_max - 1e-6)^2 (float64 bit patterns).
+      //   z <= z*  <=>  r2 <= (the largest float64 whose root rounds to z* or below: the staged "z*^2");
+      //   |z - z_max| < 1e-6  <=>  r2 > (z_max - 1e-6)^2 (float64 bit patterns).
       const float k_hit = (float)neg_half_inv_s2_log2e, k_short = (float)neg_lambda_log2e;
       const double chw = P.c_hit * P.w_hit;
       const float prw = (float)(P.p_rand * P.w_rand), wmax = (float)P.w_max;
@@ -1069,15 +1081,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
       for (int k = lane; k < B; k += 64) {
         const double r2 = __longlong_as_double((long long)beam_r2bits(k));
         double zd;
-        if constexpr (sizeof(R) == 4) {
-          // float32 square root refined by one Newton step in float64 (relative error ~1e-14);
-          // r2 <= z_max^2 holds for every entry, so the root is capped at z_max
-          const float z0 = __builtin_amdgcn_sqrtf((float)r2);
-          const double z0d = (double)z0;
-          zd = (r2 > 0.0) ? fmin(z0d + (r2 - z0d * z0d) * (double)(0.5f * __builtin_amdgcn_rcpf(z0)), P.z_max) : 0.0;
-        } else {
-          zd = sqrt(r2);
-        }
+        // (the correctly rounded root in float32 state too: the indicators below compare it with the measured range,
+        // which for a particle that stands where the measurement was taken is this very root, bit for bit)
+        zd = sqrt(r2);
         if constexpr (RNOISE) {
           // one counter block per (particle, beam in caller order); mc_localization2.py:166-173 as below
           const uint64_t gp = (uint64_t)(P.rn_index0 + p);

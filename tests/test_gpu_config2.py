@@ -1,7 +1,8 @@
 """The per-GPU share of the largest configuration -- a 16384^2 synthetic grid, 360 beams, 2^23 particles in float32
-state -- on one GPU: the map structures at that size (1.0e9 neighbourhood entries behind 32-bit offsets) against
-the oracle on a subset, the whole update through its size-independent properties, the cost of set_map, and the
-refusal just past the 2^32-entry limit."""
+state -- on one GPU: the map structures at that size (1.0e9 neighbourhood entries) against the oracle on a subset,
+the whole update through its size-independent properties, the cost of set_map; the same map size with a fifth of
+its cells occupied (4.6e9 entries: past what 32-bit offsets address), and the refusal of lists that do not fit the
+device memory allowed for them."""
 import time
 
 import numpy as np
@@ -114,19 +115,79 @@ def test_whole_update_properties(huge):
     ctx.close()
 
 
-def test_map_beyond_the_list_limit_is_refused():
-    """With every fourth cell an obstacle the neighbourhood lists of a 16384^2 map need more than 2^32 entries (a
-    query tile of 8x8 cells sees about 5100 cells within reach, 4.2e6 tiles, a quarter of the cells occupied): a clear
-    refusal, no partial state."""
+def test_dense_map_past_four_billion_list_entries():
+    """A 16384^2 map with a fifth of its cells occupied: the neighbourhood lists hold more than 2^32 entries (64-bit
+    offsets; the reference's make_obstacle_lut, mc_localization.py:61-71, has no limit of its own).  Stated bounds:
+    under 25 GB of device memory and under three minutes for set_map + set_sensor; ranges, hit cells and log-weights
+    of poses at the far end of the map -- the largest list offsets -- against the oracle."""
     from slam_amd import _lib, workload as W
-    grid = np.full((N, N), 255, np.uint8)
-    grid[::2, ::2] = 0
+    grid = W.synthetic_map(N, target_occupancy=0.2)
+    occ = float(np.mean(grid == 0))
+    assert 0.2 <= occ < 0.22
+    sp = O.SensorParams()
+    Bd = 36
+    angles = W.beam_angles(Bd)
+    ctx = _lib.Context(0, _lib.F32)
+    free0 = _free_device_bytes()
+    t0 = time.perf_counter()
+    ctx.set_map(grid, W.RES, W.RES)
+    ctx.set_sensor(angles, sp.z_max, sp.sigma_hit, sp.lambda_short, [sp.w_hit, sp.w_short, sp.w_max, sp.w_rand], 5 * np.pi / 180.0)
+    dt = time.perf_counter() - t0
+    used = free0 - _free_device_bytes()
+    print("16384^2 at %.1f %% occupancy: set_map + set_sensor %.1f s, %.2f GB of device memory" % (100 * occ, dt, used / 1e9))
+    assert used > 4.0 * (1 << 32) and used < 25e9          # more than 2^32 entries of four bytes
+    assert dt < 180.0
+    # poses in the last rows and columns of the map (offsets beyond 2^32 entries) and a few near its origin
+    rng = np.random.RandomState(8)
+    ext = N * W.RES
+    P = np.concatenate([np.stack([rng.uniform(ext - 40.0, ext - 1.0, 24), rng.uniform(ext - 40.0, ext - 1.0, 24), rng.uniform(0, 6.2, 24)], 1),
+                        np.stack([rng.uniform(1.0, 30.0, 8), rng.uniform(1.0, 30.0, 8), rng.uniform(0, 6.2, 8)], 1)])
+    P = P.astype(np.float32).astype(np.float64)
+    llut, lcell = [], []
+    for (r0, c0) in ((N - 320, N - 320), (0, 0)):           # the obstacle cells of the two corners, in list order
+        sub = grid[r0:r0 + 320, c0:c0 + 320]
+        lu, ce = O.obstacle_lut(sub)
+        ii, jj = ce // 320 + r0, ce % 320 + c0
+        llut.append(np.stack([(jj.astype(np.float32) * np.float32(W.RES)), (ii.astype(np.float32) * np.float32(W.RES))], 1))   # float32, as obstacle_lut forms them
+        lcell.append(ii.astype(np.int64) * N + jj)
+    order = np.argsort(np.concatenate(lcell), kind="stable")
+    llut, lcell = np.concatenate(llut)[order], np.concatenate(lcell)[order]
+    R, Hc = ctx.raycast(P)
+    Ro, Ho = O.sector_query_batch(P, llut, lcell, angles)
+    assert np.array_equal(R, Ro), int(np.sum(R != Ro))
+    assert np.array_equal(Hc.astype(np.int64), Ho)
+    # the float32 throughput path (interval-only kernel, records with 64-bit list offsets) on the same poses
+    z_meas = R[0]
+    M2 = 8192
+    X = np.tile(P, (M2 // len(P), 1))
+    ctx.set_particles(X)
+    ctx.shard_sample(0.0, 1e-12, 0.1, ALPHA, z_meas, np.zeros((M2, 3, 12), np.int16), 0, _lib.W_LOG)
+    lwd = ctx.get_particles(False, False, True)[2][:len(P)]
+    _, lwo, _ = O.weights_from_ranges(Ro, z_meas, O.free_cell(P[:, 0], P[:, 1], grid), sp)
+    both = np.isfinite(lwd) & np.isfinite(lwo)
+    assert np.array_equal(np.isfinite(lwd), np.isfinite(lwo)) and both.sum() >= 8
+    err = np.abs(lwd[both] - lwo[both]) / np.maximum(1.0, np.abs(lwo[both]))
+    assert err.max() < 1e-5, err.max()
+    ctx.close()
+
+
+def test_lists_beyond_the_memory_allowed_are_refused(monkeypatch):
+    """The neighbourhood lists are refused, before anything is allocated, when they would not fit the device memory
+    that is free (or the budget MCLHIP_LIST_BUDGET_GB sets): a clear message, no partial state."""
+    from slam_amd import _lib, workload as W
+    monkeypatch.setenv("MCLHIP_LIST_BUDGET_GB", "0.05")
+    grid = W.synthetic_map(2048)
     sp = O.SensorParams()
     ctx = _lib.Context(0, _lib.F32)
     ctx.set_sensor(W.beam_angles(B), sp.z_max, sp.sigma_hit, sp.lambda_short, [sp.w_hit, sp.w_short, sp.w_max, sp.w_rand],
                    5 * np.pi / 180.0)
-    with pytest.raises(_lib.MclHipError, match="2\\^32"):
+    free0 = _free_device_bytes()
+    with pytest.raises(_lib.MclHipError, match="neighbourhood lists of this map need"):
         ctx.set_map(grid, W.RES, W.RES)
+    assert free0 - _free_device_bytes() < 64 << 20
     with pytest.raises(_lib.MclHipError):
         ctx.raycast(np.array([[10.0, 10.0, 0.0]]))
+    monkeypatch.setenv("MCLHIP_LIST_BUDGET_GB", "2")
+    ctx.set_map(grid, W.RES, W.RES)                       # with room for them the same map is accepted
+    assert np.all(ctx.raycast(np.array([[10.0, 10.0, 0.0]]))[0] <= W.Z_MAX)
     ctx.close()
