@@ -84,7 +84,7 @@ RayParams make_ray_params(const mclhip_ctx* c) {
   P.tab_sorted = c->tab_sorted; P.perm = c->perm; P.lut = c->lut;
   P.ts_min = c->ts_min; P.ts_max = c->ts_max; P.inv_bw = c->inv_bw;
   P.relx = c->relx; P.G = c->G; P.ext_min = c->ext_min;
-  P.iv_NE = c->iv_NE; P.iv_NB = c->iv_NB; P.iv_cmax = c->iv_cmax; P.iv_cmin = c->iv_cmin; P.iv_edge = c->iv_edge; P.iv_beam = c->iv_beam; P.iv_lut = c->iv_lut; P.iv_ends = c->iv_ends;
+  P.iv_NE = c->iv_NE; P.iv_NB = c->iv_NB; P.iv_cmax = c->iv_cmax; P.iv_cmin = c->iv_cmin; P.iv_stride = c->iv_stride; P.iv_edge = c->iv_edge; P.iv_beam = c->iv_beam; P.iv_lut = c->iv_lut; P.iv_ends = c->iv_ends;
   P.iv_origin = c->iv_origin; P.iv_th_hi = c->iv_th_hi; P.iv_th_mid = c->iv_th_mid;
   P.half = c->half;
   P.two_pi_lo = M_PI * 2 - c->half;  // mc_localization.py:149
@@ -543,7 +543,7 @@ int mcl::set_sensor_table(mclhip_ctx* c, const double* tab_rad, int B, double z_
   {
     // Sector intervals.  Available when every beam angle lies in [0, 2 pi) and the sectors are proper arcs; edges that
     // agree to 1e-9 rad count as one (a bearing that close to either is decided by the exact test anyway).
-    c->iv_NE = 0; c->iv_NB = 0; c->iv_cmax = 0; c->iv_cmin = 0; c->iv_uniform = false;
+    c->iv_NE = 0; c->iv_NB = 0; c->iv_cmax = 0; c->iv_cmin = 0; c->iv_uniform = false; c->iv_stride = 0;
     const bool usable = c->ts_min >= 0.0 && c->ts_max < two_pi && half > 16.0 * kEdgeEps && half < 0.5 * M_PI;
     if (usable) {
       const double origin = c->ts_min - half;
@@ -613,6 +613,14 @@ int mcl::set_sensor_table(mclhip_ctx* c, const double* tab_rad, int B, double z_
         c->iv_uniform = true;
         for (int m = 0; m < NE; ++m)
           if (std::fabs(edge[m] - two_pi * m / NE) > 1e-9) c->iv_uniform = false;
+        // ... and whose sectors start at interval k * stride (sorted position k): the start needs no table then
+        if (c->iv_uniform && NE % B == 0) {
+          const int stride = NE / B;
+          bool arith = true;
+          for (int k = 0; k < B; ++k)
+            if ((beam[k] & 0x3ffu) != (unsigned)(k * stride)) arith = false;
+          if (arith) c->iv_stride = stride;
+        }
         // headings for which no sector leaves the range the reference recognises: the highest beam angle + heading +
         // half-angle stays below two turns, the lowest beam angle + heading - half-angle above minus one turn
         // (kept as centre and half-width: one subtraction and one comparison in the kernel)

@@ -58,6 +58,8 @@ struct RayParams {
   // a beam's range is the smallest of the few intervals its sector spans.  iv_NE == 0: not available for this table.
   int iv_NE, iv_NB;            // intervals (<= 1023), buckets of the look-up (a power of two)
   int iv_cmax, iv_cmin;        // most / fewest intervals a sector spans
+  int iv_stride;               // > 0: the sector of the beam at sorted position k starts at interval k * iv_stride (evenly
+                               // spaced beams whose spacing divides the sector's width): no table read to find it
   const float* iv_edge;        // [NE + 1] lower edge of every interval, measured from iv_origin; iv_edge[NE] = 2 pi
   const uint16_t* iv_beam;     // [B] first interval | number of intervals (<= 63) << 10 of the beam at sorted position k
   const uint16_t* iv_lut;      // [NB] bucket -> last interval that starts at or below the bucket's lower edge
@@ -175,7 +177,7 @@ struct mclhip_ctx {
   uint16_t* inv_perm = nullptr;
   uint16_t* lut = nullptr;
   float* iv_edge = nullptr; uint16_t* iv_beam = nullptr; uint16_t* iv_lut = nullptr; uint32_t* iv_ends = nullptr;   // sector intervals (see RayParams)
-  int iv_NE = 0, iv_NB = 0, iv_cmax = 0, iv_cmin = 0; double iv_origin = 0.0, iv_th_hi = 0.0, iv_th_mid = 0.0; bool iv_uniform = false;   // (uniform: the intervals are equally wide)
+  int iv_NE = 0, iv_NB = 0, iv_cmax = 0, iv_cmin = 0, iv_stride = 0; double iv_origin = 0.0, iv_th_hi = 0.0, iv_th_mid = 0.0; bool iv_uniform = false;   // (uniform: the intervals are equally wide)
   float* relx = nullptr;
   int G = 0;
   double ext_min = 0;

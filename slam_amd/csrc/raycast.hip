@@ -423,6 +423,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
   const float iv_near_uf = 0.5f - iv_nearf * (float)((double)P.iv_NE / kTwoPi);   // UNIF: the same band in interval widths, from the middle
   const float iv_inv_wf = (float)((double)P.iv_NE / kTwoPi);   // UNIF: intervals per radian
   const float iv_nf = (float)P.iv_NE;                          // ... and per turn
+  const float iv_nf_below = __uint_as_float(__float_as_uint(iv_nf) - 1u);   // the largest float32 below the interval count
+  const int lane_run = (int)(threadIdx.x & 63) * P.iv_stride;   // UNIF > 0: where the sector of the lane's first beam starts
 
   const unsigned long long r2max_bits = (unsigned long long)__double_as_longlong(P.r2max);
   const float disk_r = (float)(P.z_max * (1.0 + 1e-5) + 0.02 * (P.res_x < P.res_y ? P.res_x : P.res_y));
@@ -582,10 +584,16 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
             // (the place is not negative and the conversion truncates towards zero: only the upper end needs a clamp; NaN
             // converts to 0.  The product is within 4e-7 rad of the true place: the band below allows for it, and a
             // bearing that lands one interval off is within the band of the edge between the two, which is what counts)
-            const float au = IVONLY ? place * iv_nf : a * iv_inv_wf;
-            m = (int)au;
-            m = m > IVN - 1 ? IVN - 1 : m;
-            uf = au - (float)m;        // place inside the interval, in interval widths
+            if constexpr (IVONLY) {
+              const float au = fminf(place * iv_nf, iv_nf_below);   // [0, N): the conversion needs no clamp, and
+              m = (int)au;
+              uf = __builtin_amdgcn_fractf(au);                      // the place inside the interval is its fraction
+            } else {
+              const float au = a * iv_inv_wf;
+              m = (int)au;
+              m = m > IVN - 1 ? IVN - 1 : m;
+              uf = au - (float)m;      // place inside the interval, in interval widths
+            }
           } else {
             int bkt = (int)(a * iv_inv_bwf);
             bkt = bkt < 0 ? 0 : (bkt > P.iv_NB - 1 ? P.iv_NB - 1 : bkt);
@@ -598,14 +606,18 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
           }
           bool at_lower, near_edge;
           if constexpr (UNIF != 0) {
-            near_edge = !(fabsf(uf - 0.5f) <= iv_near_uf);                          // also NaN
+            const bool inside = fabsf(uf - 0.5f) <= iv_near_uf;
+            near_edge = !inside;                                                    // also NaN
             at_lower = !(uf >= 0.5f);
           } else {
             at_lower = !(a - e0 >= iv_nearf);                                       // also NaN
             near_edge = at_lower || !(e1 - a >= iv_nearf);
           }
-          if (hit && !near_edge) atomicMin(&imin[m], r2bits);
-          if (hit && near_edge) {
+          // (nested, not two conditions side by side: the mask of the second branch is then the first one's
+          // complement, formed by a scalar instruction instead of a second vector comparison)
+          if (hit) {
+          if (!near_edge) atomicMin(&imin[m], r2bits);
+          else {
             // within rounding of edge E: parked, decided in float64 after the walk (rare; keeps the call out of this loop)
             COUNTL(2);
             const unsigned int E = (unsigned int)(at_lower ? m : (m + 1 == IVN ? 0 : m + 1));
@@ -613,6 +625,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
             if (pos < (unsigned int)kEdgeQueue) edgeq[pos] = ((unsigned long long)E << 32) | e;
             else lane_redo = true;
             lane_parked = true;
+          }
           }
           hit = false;
         }
@@ -895,9 +908,10 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
       if (!use_iv) rb = rmin[G + k];
       if constexpr (IVK) {
         if (use_iv) {
-          const unsigned int span_k = s_ivbeam[k];
-          const unsigned long long* run = imin + (span_k & 0x3ffu);
-          const int cnt = (int)(span_k >> 10);
+          // (UNIF > 0: launched only for tables whose sectors start at k * iv_stride and span UNIF intervals each)
+          const unsigned int span_k = UNIF > 0 ? 0u : s_ivbeam[k];
+          const unsigned long long* run = imin + (UNIF > 0 ? (unsigned int)(lane_run + (k - lane) * P.iv_stride) : (span_k & 0x3ffu));
+          const int cnt = UNIF > 0 ? UNIF : (int)(span_k >> 10);
           double best = P.r2max;
           // (the plain instruction: nothing here is a NaN, so the library minimum's quieting of operands is not needed)
           auto lower = [](double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
@@ -1028,7 +1042,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
         const double mant = __longlong_as_double((bits & 0x000fffffffffffffll) | 0x3ff0000000000000ll);
         return (double)(ex - 1023) + (double)__builtin_amdgcn_logf((float)mant);
       };
-      for (int k = lane; k < B; k += 64) {
+      auto beam_factor = [&](int k) {
         const unsigned long long rb = beam_r2bits(k);
         const double r2 = __longlong_as_double((long long)rb);
         const float num = (float)(r2 - s_zt[k]);                      // z^2 - z*^2, cancellation exact in float64
@@ -1043,15 +1057,28 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
         float small = prw;                                            // p_rand * w_rand
         small = small + (num <= 0.0f ? e_short * zf.y : 0.0f);        // p_short * w_short where z <= z*
         small = small + (rb > near_max_bits ? wmax : 0.0f);           // p_max * w_max
-        const double pk = (double)e_hit * chw + (double)small;        // + p_hit * w_hit
-        prod *= pk;
-        if (++nfac == 16) {                                           // sixteen factors >= 1e-3 cannot underflow
-          l2s += log2_of_product(prod);
-          prod = 1.0;
-          nfac = 0;
+        return (double)e_hit * chw + (double)small;                   // + p_hit * w_hit
+      };
+      if constexpr (STATIC_L && CAP / 64 <= 16) {
+        // the fixed layout's beam count is at most CAP: a lane has CAP / 64 beams at most, one after the other without
+        // a loop (its counter, its bound and the partial product's count are gone: 12 instructions of 45 per round)
+#pragma unroll
+        for (int it = 0; it < CAP / 64; ++it) {
+          const int k = lane + 64 * it;
+          if (k < B) prod *= beam_factor(k);
         }
+        l2s = log2_of_product(prod);
+      } else {
+        for (int k = lane; k < B; k += 64) {
+          prod *= beam_factor(k);
+          if (++nfac == 16) {                                         // sixteen factors >= 1e-3 cannot underflow
+            l2s += log2_of_product(prod);
+            prod = 1.0;
+            nfac = 0;
+          }
+        }
+        if (nfac) l2s += log2_of_product(prod);
       }
-      if (nfac) l2s += log2_of_product(prod);
       const double lsd = wave_sum_fixed(l2s) * 0.6931471805599453;
       if constexpr (IVONLY) {
         if (lane == 0) outbuf[out_slot] = on_free ? lsd : -INFINITY;
@@ -1315,9 +1342,10 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
       P.redo_list = c->redo_list; P.redo_count = c->redo_count;
       timing_begin(c, 0);
       const bool even = c->iv_uniform, same = c->iv_cmin == c->iv_cmax;     // equally wide intervals; as many per sector
-      if (cap == 192 && even && same && c->iv_cmax == 5) MCL_RAY_U(float, false, false, false, true, kWavesPerBlock, true, false, 192, 5);
+      const bool arith = c->iv_stride > 0;                                   // sectors start at k * stride: the UNIF > 0 variants
+      if (cap == 192 && even && same && arith && c->iv_cmax == 5) MCL_RAY_U(float, false, false, false, true, kWavesPerBlock, true, false, 192, 5);
       else if (cap == 192 && even) MCL_RAY_U(float, false, false, false, true, kWavesPerBlock, true, false, 192, -1);
-      else if (cap == 384 && even && same && c->iv_cmax == 10) MCL_RAY_U(float, false, false, false, true, 2 * kWavesPerBlock, true, false, 384, 10);
+      else if (cap == 384 && even && same && arith && c->iv_cmax == 10) MCL_RAY_U(float, false, false, false, true, 2 * kWavesPerBlock, true, false, 384, 10);
       else if (cap == 384 && even) MCL_RAY_U(float, false, false, false, true, 2 * kWavesPerBlock, true, false, 384, -1);
       else if (cap == 192) MCL_RAY_W(float, false, false, false, true, kWavesPerBlock, true, false, 192);
       else if (cap == 384) MCL_RAY_W(float, false, false, false, true, 2 * kWavesPerBlock, true, false, 384);
