@@ -284,12 +284,14 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
   double* s_el = s_zt + LNT;                                      // [NT] eta*lambda (GRID: exp(-lambda * z_meas))
   unsigned long long* s_rmin_all = reinterpret_cast<unsigned long long*>(s_el + LNT);
   const int NXP = IVONLY ? 0 : P.G + B + kGroup;                 // extended table + one group of padding
-  const int RS = NXP + NE + (GRID ? B : 0);                      // per wave: minima per table entry, then (GRID) per entry, and a double per class
+  // per wave: minima per table entry (GRID: or per interval, whichever array is longer), then (GRID) per entry, and a double per class
+  const int NXQ = GRID ? (NXP > P.iv_NE + P.iv_cmax ? NXP : P.iv_NE + P.iv_cmax) : NXP;
+  const int RS = NXQ + NE + (GRID ? B : 0);
   // With sector intervals (see RayParams::iv_*; not for the staged query, which also wants the hit cell, nor for the
   // histogram filter's classes) the wave's table holds the smallest squared distance per INTERVAL -- iv_NE entries and
   // the first iv_cmax again behind them, so that a sector that wraps reads on -- for a particle that takes the interval
   // path, and per table entry for one that does not: one array, sized for the larger of the two.
-  constexpr bool IVK = !STAGE && !GRID;
+  constexpr bool IVK = !STAGE;   // (GRID: the class table's intervals, when every sector spans at most two -- the host says so by leaving iv_NE set)
   const int IVN = IVK ? P.iv_NE : 0;
   const int IVS = IVK ? P.iv_NE + P.iv_cmax : 0;
   const int LIVN = STATIC_L ? CAP : IVN;
@@ -305,8 +307,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
   double* s_ang = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(s_cls + NE) + 7) & ~(uintptr_t)7);   // [B0] beam angles, [D] heading angles (radians)
   unsigned short* s_member = reinterpret_cast<unsigned short*>(s_ang + (GRID ? P.g_B0 + P.g_D : 0));   // [NE] entries by class
   unsigned short* s_first = s_member + NE;                                                     // [B + 1] start of every class in s_member
-  // the interval tables (never together with GRID) stand where the class tables would
-  float* s_ivedge = reinterpret_cast<float*>(s_cls);                                           // [IVN + 1]
+  // the interval tables stand where the class tables would (GRID: behind them)
+  float* s_ivedge = GRID ? reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(s_first + B + 1) + 3) & ~(uintptr_t)3)
+                         : reinterpret_cast<float*>(s_cls);                                    // [IVN + 1]
   unsigned short* s_ivbeam = reinterpret_cast<unsigned short*>(s_ivedge + LIVN + 1);           // [B]
   unsigned short* s_ivlut = s_ivbeam + LB;                                                      // [iv_NB]
   unsigned int* s_ivends = reinterpret_cast<unsigned int*>(s_ivlut + ((LNBI + LB + 1) & ~1) - LB);   // [IVN], 4-byte aligned
@@ -362,7 +365,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
   const int lane0 = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: particle index, pose and slice bounds live in scalar registers
   unsigned long long* const rmin = s_rmin_all + (size_t)wv * TS;   // per extended-table entry (or per interval): bits of the smallest r2
-  unsigned long long* const emin = rmin + NXP;                     // GRID: per entry, what only its own angle let in
+  unsigned long long* const emin = rmin + NXQ;                     // GRID: per entry, what only its own angle let in
   unsigned long long* const aux = s_aux_all + (size_t)wv * RS;     // STAGE: hit cell per entry; PRODUCT: p_k in caller order
   unsigned int* const ring = s_walk_all + (size_t)wv * kWaveScratch;   // [128] cells waiting to be matched
   unsigned long long* const edgeq = reinterpret_cast<unsigned long long*>(ring + 128);   // [kEdgeQueue] edge << 32 | cell
@@ -742,7 +745,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
 #pragma unroll
         for (int j = 0; j < CAP; j += 64) rmin[lane + j] = r2max_bits;
       } else {
-        const int n_clear = use_iv ? IVN : RS;
+        const int n_clear = (use_iv && !GRID) ? IVN : RS;   // (GRID: the minima per entry behind the intervals as well)
         for (int k = lane; k < n_clear; k += 64) {
           rmin[k] = r2max_bits;
           if (STAGE) aux[k] = 0xffffffffull;
@@ -863,11 +866,37 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
               const double de = fabs((s_ts[k] + th) - a_exact);      // :143, :148
               return !((de <= P.half) || (de >= P.two_pi_lo && de <= P.two_pi_hi));   // :149
             };
+            if constexpr (GRID) {
+              // Histogram filter: the entries of a class are asked one by one, each with its own unreduced angle
+              // (robot.py:252-258 -- where the last bits of an angle decide, entries of one class may differ), and what
+              // an entry accepts goes to the entry's own minimum.  The class that ends at the edge, the one that
+              // starts there, and the one that holds the edge in its interior (sectors span two intervals at most:
+              // it is the class whose sector starts an interval earlier), which accepts without being asked.
+              auto give = [&](unsigned int cc, bool ask) {
+                for (int mm = s_first[cc]; mm < s_first[cc + 1]; ++mm) {
+                  const unsigned int me = s_member[mm], ck = s_cls[me];
+                  bool ok = true;
+                  if (ask) {
+                    const double beta = s_ang[ck & 0x3ffu] + s_ang[P.g_B0 + ((ck >> 10) & 0x3ffu)];   // robot.py:252
+                    const double de = fabs((beta + th) - a_exact);
+                    ok = (de <= P.half) || (de >= P.two_pi_lo && de <= P.two_pi_hi);
+                  }
+                  if (ok) atomicMin(&emin[me], r2bits);
+                }
+              };
+              if ((ends >> 10) & 1u) give(ends & 0x3ffu, true);
+              if ((ends >> 21) & 1u) give((ends >> 11) & 0x3ffu, true);
+              if ((ends >> 22) & 1u) {
+                const unsigned int prev = s_ivends[left];
+                if ((prev >> 21) & 1u) give((prev >> 11) & 0x3ffu, false);
+              }
+            } else {
             const bool no_end = ((ends >> 10) & 1u) && refuses(ends & 0x3ffu);
             const bool no_start = ((ends >> 21) & 1u) && refuses((ends >> 11) & 0x3ffu);
             if (!no_end) atomicMin(&imin[left], r2bits);
             else if (no_start && ((ends >> 22) & 1u)) lane_redo = true;
             if (!no_start) atomicMin(&imin[right], r2bits);
+            }
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
@@ -957,10 +986,17 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
       // what depends on the predicted range alone -- the root and the normaliser of the short-reading
       // term (range_sensor.py:48) -- once per class; an entry that its own angle gave a nearer cell redoes it
       double* const etac = reinterpret_cast<double*>(emin + NE);
+      // (with sector intervals a class's squared range is the smaller of its intervals', and its root goes where the
+      // intervals stood: every class reads first -- the roots wait in the other array meanwhile)
+      const int zoff = use_iv ? 0 : G;
+      if (use_iv) {
+        for (int cc = lane; cc < B; cc += 64) etac[cc] = sqrt(__longlong_as_double((long long)beam_r2bits(cc)));   // robot.py:269
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      }
       for (int cc = lane; cc < B; cc += 64) {
-        const double z = sqrt(__longlong_as_double((long long)rmin[G + cc]));   // robot.py:269
+        const double z = use_iv ? etac[cc] : sqrt(__longlong_as_double((long long)rmin[G + cc]));   // robot.py:269
         etac[cc] = 1.0 / (1.0 - exp(-P.lambda * z));
-        rmin[G + cc] = (unsigned long long)__double_as_longlong(z);
+        rmin[zoff + cc] = (unsigned long long)__double_as_longlong(z);
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       // p(z_meas | z_pred) of one entry (range_sensor.py:95-112 called from robot.py:297)
@@ -979,7 +1015,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
       auto own_range = [&](unsigned int k) {
         const unsigned int ck = s_cls[k];
         const int cc = (int)(ck >> 20);
-        double z = __longlong_as_double((long long)rmin[G + cc]);
+        double z = __longlong_as_double((long long)rmin[zoff + cc]);
         double eta = etac[cc];
         const double zo = sqrt(__longlong_as_double((long long)emin[k]));
         if (zo < z) { z = zo; eta = 1.0 / (1.0 - exp(-P.lambda * z)); }
@@ -992,7 +1028,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
         if (k < NE) {
           const unsigned int ck = s_cls[k];
           const int cc = (int)(ck >> 20);
-          const double z = __longlong_as_double((long long)rmin[G + cc]);
+          const double z = __longlong_as_double((long long)rmin[zoff + cc]);
           const unsigned long long me = emin[k];
           own = (me != r2max_bits) && (__longlong_as_double((long long)me) <= z * z * (1.0 + 1e-15));
           if (!own) emin[k] = (unsigned long long)__double_as_longlong(entry_px((int)(ck & 0x3ffu), z, etac[cc]));   // in place: the minimum is spent
@@ -1194,7 +1230,8 @@ static size_t ray_lds_bytes(int B, int G, int NB, bool aux, int waves = kWavesPe
   }
   const int NXP = ivonly ? 0 : B + G + kGroup;
   const int NT = NE ? B0 : B;
-  const int RS = NXP + NE + (NE ? B : 0);
+  const int NXQ = NE ? std::max(NXP, iv_NE + iv_cmax) : NXP;                   // (histogram filter: class minima or interval minima, then per entry)
+  const int RS = NXQ + NE + (NE ? B : 0);
   const int TS = std::max(RS, iv_NE ? iv_NE + iv_cmax : 0);                    // per-wave table: per entry or per interval
   size_t s = (size_t)(B + 2 * NT) * sizeof(double);
   s += (size_t)waves * (TS + (aux ? RS : 0)) * sizeof(unsigned long long);
@@ -1220,18 +1257,23 @@ int launch_grid_update(mclhip_ctx* c, const double* d_x, const double* d_y, cons
   P.g_cell = d_cell; P.g_D = n_dir; P.g_B0 = beams_per_dir; P.g_pk_pred = pk_pred; P.g_pk = pk;
   P.g_NE = c->gl_NE; P.g_cls = c->gl_cls; P.g_cls_first = c->gl_cls_first; P.g_member = c->gl_member; P.g_ar = c->gl_mbeta; P.g_thd = c->gl_mbeta + beams_per_dir;
   P.zt = c->gl_zt; P.etalam = c->gl_el;   // per beam of one heading
+  // Sector intervals of the class table, where every sector spans at most two of them (the cell on a sector edge is
+  // then decided against the one class that ends there, the one that starts there and the one that holds the edge
+  // in its interior -- see the kernel); other tables run window by window.
+  if (!MCL_FAST_INTERVALS || P.iv_NE <= 0 || P.iv_cmax > 2) { P.iv_NE = 0; P.iv_cmax = 0; P.iv_NB = 0; }
   // as many waves per block as the LDS holds: 16, 12, 8 or 4
   const size_t lds_max = 160 * 1024;
   int waves = 16;
-  while (waves > 4 && ray_lds_bytes(P.B, P.G, P.NB, false, waves, P.g_NE, P.g_B0) > lds_max) waves -= 4;
-  const size_t lds = ray_lds_bytes(P.B, P.G, P.NB, false, waves, P.g_NE, P.g_B0);
+  while (waves > 4 && ray_lds_bytes(P.B, P.G, P.NB, false, waves, P.g_NE, P.g_B0, P.iv_NE, P.iv_NB, P.iv_cmax) > lds_max) waves -= 4;
+  const size_t lds = ray_lds_bytes(P.B, P.G, P.NB, false, waves, P.g_NE, P.g_B0, P.iv_NE, P.iv_NB, P.iv_cmax);
   if (lds > lds_max) return fail(c, MCLHIP_E_LIMIT, "heading x beam table does not fit the kernel's LDS budget");
   int64_t blocks = (n + waves - 1) / waves;
   const int64_t max_blocks = 256 * 8 * 4 * 4 / waves;
   if (blocks > max_blocks) blocks = max_blocks;
-#define MCL_GRID(W)                                                                                                   \
+#define MCL_GRID(W) do { if (P.iv_NE > 0 && c->iv_uniform) MCL_GRID_U(W, -1); else MCL_GRID_U(W, 0); } while (0)
+#define MCL_GRID_U(W, U)                                                                                              \
   do {                                                                                                                \
-    auto kern = raycast_kernel<double, false, false, true, W>;                                                        \
+    auto kern = raycast_kernel<double, false, false, true, W, false, false, false, false, 0, U>;                      \
     if (lds > 48 * 1024)                                                                                              \
       MCL_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                      (int)lds));                                                                      \
@@ -1244,6 +1286,7 @@ int launch_grid_update(mclhip_ctx* c, const double* d_x, const double* d_y, cons
   else if (waves == 8) MCL_GRID(8);
   else MCL_GRID(4);
 #undef MCL_GRID
+#undef MCL_GRID_U
   MCL_HIP(c, hipGetLastError());
   return MCLHIP_OK;
 }
