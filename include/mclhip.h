@@ -480,9 +480,12 @@ int mclhip_fs_dshard_unpack(mclhip_ctx* ctx, const void* d_rows, const void* d_f
  *            particles of the sector-interval path), 1 = motion kernel,
  *        2 = normalise + resample + gather kernels together,
  *        3 = grid prediction, 4 = grid update,
- *        5 = the sector query's second launch (the particles the first left over), only with on = 1;
- *        6 = no timing: *launches = how many particles the last two-launch sector query left to its second launch
- *            (the count the host last saw: written behind that launch, never waited for).
+ *        5 = the sector query's launches after the first (the particles the first left over), only with on = 1;
+ *        6 = no timing: *launches = how many particles the last two-launch sector query left to its entry-by-entry
+ *            launch (the count the host last saw: written behind that launch, never waited for);
+ *        7 = likewise, what the first launch left over: the same number, unless the interval kernel made a second
+ *            pass over that list in between (evenly spaced beams; headings outside the range in which the
+ *            reference's predicate is the circular one; see MCLHIP_EVERY_HEADING in the integration notes).
  * on: 0 off, 1 every group, 2 the sector-query kernel only (two events per step instead of six: an event between
  * two kernels costs a few microseconds of idle GPU).  Enabling resets the accumulators. */
 int mclhip_timing_enable(mclhip_ctx* ctx, int on);

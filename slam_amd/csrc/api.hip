@@ -166,7 +166,10 @@ int build_ring_table(mclhip_ctx* c) {
     }
   }
   MCL_HIP(c, hipMalloc((void**)&c->nbr_off, (ne + 1) * sizeof(uint64_t)));
-  MCL_HIP(c, hipMalloc((void**)&c->nbr_cells, (size_t)(acc ? acc : 1) * sizeof(uint32_t)));
+  // (kListReadAhead entries behind the last list: a kernel that asks for a list's batches ahead of knowing where it ends
+  // may read that far beyond it)
+  MCL_HIP(c, hipMalloc((void**)&c->nbr_cells, (size_t)(acc + kListReadAhead) * sizeof(uint32_t)));
+  MCL_HIP(c, hipMemsetAsync(c->nbr_cells + acc, 0, kListReadAhead * sizeof(uint32_t), c->stream));
   MCL_HIP(c, hipMemcpy(c->nbr_off, off.data(), (ne + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
   rc = launch_nbr_fill(c);
   if (rc != MCLHIP_OK) return rc;
@@ -211,7 +214,8 @@ static int ensure_capacity(mclhip_ctx* c, int64_t M) {
   MCL_TRY(dev_alloc(c, &c->bases, M * run_base_bytes()));
   MCL_TRY(dev_alloc(c, &c->idx, M * sizeof(int64_t)));
   MCL_TRY(dev_alloc(c, &c->redo_list, (M + mclhip_ctx::kRedoSlack) * sizeof(int32_t)));
-  MCL_TRY(dev_alloc(c, &c->redo_count, 64 * sizeof(uint32_t)));
+  MCL_TRY(dev_alloc(c, &c->redo_list2, (M + mclhip_ctx::kRedoSlack) * sizeof(int32_t)));
+  MCL_TRY(dev_alloc(c, &c->redo_count, 2 * 64 * sizeof(uint32_t)));   // (one set of counts per list)
   c->redo_cap = M;
   if (c->dtype == MCLHIP_F32) MCL_TRY(dev_alloc(c, &c->qrec, (size_t)M * sizeof(QueryRecord)));
   if (c->noise) { (void)hipFree(c->noise); c->noise = nullptr; }
@@ -281,6 +285,7 @@ void make_query_prep(const mclhip_ctx* c, QueryPrep& qp) {
   qp.inv_res_xf = (float)(1.0 / c->res_x); qp.inv_res_yf = (float)(1.0 / c->res_y);
   qp.th_mid = (float)c->iv_th_mid; qp.th_hi = (float)c->iv_th_hi;
   qp.origin = (float)c->iv_origin;
+  qp.serve_all = ray_serves_every_heading(c) ? 1 : 0;
 }
 
 // the same for code outside this file (the sector query marks its own launches)
@@ -372,8 +377,9 @@ int mclhip_create(mclhip_ctx** out, int device, int dtype) {
   if (e == hipSuccess) e = hipMalloc((void**)&c->scal, 8 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&c->stamps, 16 * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMemset(c->stamps, 0, 16 * sizeof(unsigned long long));
-  if (e == hipSuccess) e = hipHostMalloc((void**)&c->redo_hint, 64 * sizeof(uint32_t), hipHostMallocDefault);
-  if (e == hipSuccess) std::memset(c->redo_hint, 0, 64 * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c->redo_hint, 128 * sizeof(uint32_t), hipHostMallocDefault);
+  if (e == hipSuccess) std::memset(c->redo_hint, 0, 128 * sizeof(uint32_t));
+  if (const char* m = std::getenv("MCLHIP_EVERY_HEADING")) c->every_heading = (m[0] == '0') ? 0 : (m[0] == '1' ? 1 : -1);
   if (const char* m = std::getenv("MCLHIP_SPLIT")) c->split_mode = (m[0] == '0') ? 0 : (m[0] == '1' ? 1 : -1);
   if (e == hipSuccess) resolve_static_scratch(device);
   if (e != hipSuccess) {
@@ -390,7 +396,7 @@ void mclhip_destroy(mclhip_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   fs_release(c);
-  void* ptrs[] = {c->obst, c->freeb, c->tile_off, c->cells, c->nbr_off, c->nbr_cells, c->tab_sorted, c->tab_orig, c->perm, c->inv_perm, c->lut, c->relx, c->iv_edge, c->iv_beam, c->iv_lut, c->iv_ends, c->redo_list, c->redo_count, c->qrec, c->zt, c->etalam, c->zmeas_stage, c->ring,
+  void* ptrs[] = {c->obst, c->freeb, c->tile_off, c->cells, c->nbr_off, c->nbr_cells, c->tab_sorted, c->tab_orig, c->perm, c->inv_perm, c->lut, c->relx, c->iv_edge, c->iv_beam, c->iv_lut, c->iv_ends, c->redo_list, c->redo_list2, c->redo_count, c->qrec, c->zt, c->etalam, c->zmeas_stage, c->ring,
                   c->px[0], c->px[1], c->py[0], c->py[1], c->pth[0], c->pth[1], c->w[0], c->w[1], c->logw, c->pm,
                   c->sx, c->sy, c->sth, c->sw, c->chunk_sums, c->scal, c->cdf_approx, c->cdf_exact, c->kscan,
                   c->fscan, c->blk_a, c->blk_b, c->irr, c->bases, c->idx, c->noise, c->counters, c->range_noise, c->inj_rows, c->stamps,
@@ -1448,10 +1454,13 @@ int mclhip_timing_get(mclhip_ctx* c, int which, int64_t* launches, double* total
     if (total_ms) *total_ms = (double)v;
     return MCLHIP_OK;
   }
-  if (c && which == 6) {   // particles the last two-launch sector query left to its second launch, as the host last saw it
+  if (c && (which == 6 || which == 7)) {
+    // particles the last two-launch sector query left over, as the host last saw it: 6 -- to the entry-by-entry launch;
+    // 7 -- by the first launch (the same, unless the arithmetic interval kernel made its second pass in between)
     uint64_t left = 0;
+    const int from = (which == 6 && c->every_last) ? 64 : 0;
     if (c->redo_hint)
-      for (int k = 0; k < 64; ++k) left += reinterpret_cast<volatile uint32_t*>(c->redo_hint)[k];
+      for (int k = 0; k < 64; ++k) left += reinterpret_cast<volatile uint32_t*>(c->redo_hint)[from + k];
     if (launches) *launches = (int64_t)left;
     if (total_ms) *total_ms = 0.0;
     return MCLHIP_OK;

@@ -253,8 +253,11 @@ __global__ __launch_bounds__(256) void motion_kernel(T* __restrict__ xs, T* __re
     const QueryPrep& q = mp.qp;
     QueryRecord rec;
     rec.x = (float)sx; rec.y = (float)sy; rec.th = (float)st;
-    rec.tho = (rec.th + q.origin) * 0.15915494309189535f;
-    const bool served = fabsf(rec.th - q.th_mid) <= q.th_hi;
+    // (reduced to [0, 1] in float64: a heading many turns away would leave a float32 quotient no fraction bits)
+    const double turns = ((double)rec.th + (double)q.origin) * 0.15915494309189535;
+    rec.tho = (float)(turns - floor(turns));
+    const bool circular = fabsf(rec.th - q.th_mid) <= q.th_hi;
+    const bool served = circular || (q.serve_all && fabsf(rec.th) < INFINITY);
     const float fxc = rec.x * q.inv_res_xf, fyc = rec.y * q.inv_res_yf;
     const bool pose_ok = (fabsf(fxc) < 1.0e6f) && (fabsf(fyc) < 1.0e6f);   // far outside any map, or NaN: no tile
     uint64_t first = 0ull;
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(256) void motion_kernel(T* __restrict__ xs, T* __re
       }
     }
     rec.first_lo = (uint32_t)first; rec.first_hi = (uint32_t)(first >> 32); rec.n_cells = n_cells;
-    rec.flags = (fr ? 1u : 0u) | (served ? 2u : 0u);
+    rec.flags = (fr ? 1u : 0u) | (circular ? 2u : 0u) | (served && !circular ? 4u : 0u);
     uint4* dst = reinterpret_cast<uint4*>(&q.out[i]);
     const uint4* src = reinterpret_cast<const uint4*>(&rec);
     dst[0] = src[0];

@@ -114,13 +114,18 @@ struct RayParams {
 // are used (scalar loads share their counter with LDS: the first LDS read after one waits for it) -- and starts on
 // the particle's list of cells without computing a tile or waiting for the tile's bounds (a dependent read from HBM
 // per particle).
+constexpr int kListReadAhead = 256;   // entries of RayParams::nbr_cells that may be read beyond the end of a list (allocated behind the last)
 struct QueryRecord {
   float x, y, th;        // the pose as stored (float32 state)
   float tho;             // (heading + angle of interval edge 0) in turns: a bearing in turns minus this, its fraction
                          // taken, is the bearing's place on the circle of sector intervals
   uint32_t first_lo, first_hi;   // the slice of RayParams::nbr_cells the particle has to look at starts here (64 bits) ...
   uint32_t n_cells;      // ... and is this long (whole batches of 64)
-  uint32_t flags;        // bit 0: the pose rounds to a free cell; bit 1: the heading is one the interval path serves
+  uint32_t flags;        // bit 0: the pose rounds to a free cell; bit 1: the heading is in the range in which the
+                         // reference's predicate is the circular one (the interval path's first launch serves it);
+                         // bit 2: a finite heading outside that range, for the second pass of the arithmetic interval
+                         // kernel, which restores what the reference does at the seam of the bearings and for beam
+                         // angles two or more turns away.  The slice is filled in for either.
 };
 static_assert(sizeof(QueryRecord) == 32, "two 16-byte loads");
 struct QueryPrep {
@@ -130,6 +135,7 @@ struct QueryPrep {
   float inv_res_xf, inv_res_yf;
   float th_mid, th_hi;   // |heading - th_mid| <= th_hi: served by the interval path (RayParams::iv_th_*)
   float origin;          // RayParams::iv_origin
+  int serve_all;         // every finite heading is served (the interval-only kernel at hand handles the ones outside the range)
 };
 
 struct MotionParams {
@@ -198,6 +204,7 @@ struct mclhip_ctx {
 
   // particles (structure of arrays; pose arrays are float or double by dtype)
   int64_t M = 0, cap = 0;
+  int32_t* redo_list2 = nullptr;   // ... and what the second pass over that list left over in turn (its counts: redo_count + 64)
   int32_t* redo_list = nullptr; uint32_t* redo_count = nullptr; int64_t redo_cap = 0;   // particles the interval-only sector query left over
   mcl::QueryRecord* qrec = nullptr;   // [cap] the motion kernel's records for the interval-only sector query
   static constexpr int64_t kRedoSlack = 64 * 16 * 2;   // the 64 lists are rounded up to whole blocks of waves
@@ -207,6 +214,14 @@ struct mclhip_ctx {
   // runs as one kernel, which serves such a cloud faster than two launches do, and probes again every eighth query.
   uint32_t* redo_hint = nullptr;
   std::string query_kernel;     // the sector-query instantiation the last query ran (its first launch, if it ran as two)
+  // Headings outside the circular range (QueryRecord::flags bit 2): the arithmetic interval kernel can serve them in a
+  // second pass, over the list of what the first launch left, before the entry-by-entry launch takes what is then
+  // still left.  -1: when the first launch last left between a sixteenth and half of the cloud (a shorter list is served
+  // as fast entry by entry -- the extra launch has a fixed cost; a longer one faster by the one kernel that holds both
+  // paths, see split_mode.  Measured at 2^20 x 180: 3 % left over 0.749 against 0.750 ms a step, 17 % 0.870 against
+  // 0.900, all of them 1.61 against 1.36); 0 never; 1 always (environment MCLHIP_EVERY_HEADING).
+  int every_heading = -1;
+  bool every_last = false;      // the last query made that second pass
   int split_mode = -1;          // -1 by the hint, 0 never two launches, 1 always (environment MCLHIP_SPLIT at creation)
   int64_t split_skipped = 0;
   void* px[2] = {nullptr, nullptr};
@@ -322,6 +337,10 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
                    const QueryRecord* qrec = nullptr);
 // fills mp.qp so that the motion kernel leaves the records of the sector query that follows (or out = null: none)
 void make_query_prep(const mclhip_ctx* c, QueryPrep& qp);
+// > 0: the beam table at hand is one of the interval-only kernel's arithmetic layouts (that many intervals per sector)
+int ray_arith_span(const mclhip_ctx* c);
+// ... and that kernel also serves the headings outside the circular range
+bool ray_serves_every_heading(const mclhip_ctx* c);
 int launch_mean_weight(mclhip_ctx* c);
 int launch_sequential_total(mclhip_ctx* c);   // c->cdf_exact = strictly sequential running sum of the live weights
 void fs_release(mclhip_ctx* c);

@@ -57,9 +57,10 @@ constexpr int kWavesPerBlock = MCL_WPB;
 constexpr int kGroup = MCL_GROUP;   // beams examined per step of the matching loop
 constexpr int kCapSpan = 16;
 constexpr int cap_buckets(int cap) { int n = 1; while (n < 2 * cap) n <<= 1; return n; }
-constexpr int kEdgeQueue = 32;        // cells on a sector edge that a particle can park (interval path); more: the particle is done entry by entry
+constexpr int kEdgeQueue = 64;        // cells on a sector edge that a particle can park (interval path); more: the particle is done entry by entry
 constexpr int kSubLists = 64;         // the list of left-over particles is kept as this many lists with a counter each (blocks b, b + 64, ... share one)
 constexpr int kFiled = 16;            // particles an interval-only wave notes before it appends them to the list in one go
+constexpr int kSeamSlots = 64;        // beams near the seam of the bearings whose cells there are asked one by one (interval-only kernel, headings outside the circular range)
 constexpr int kWaveScratch = 128 + 2 * kEdgeQueue + 2 + kFiled + 2;   // u32 words of per-wave LDS scratch: the ring of cells waiting to be matched, the parked cells (u64 each), their count, the noted particles, their count
 
 // ---- cross-lane helpers on the DPP path (no LDS round trip) ----------------
@@ -296,7 +297,11 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
   const int IVS = IVK ? P.iv_NE + P.iv_cmax : 0;
   const int LIVN = STATIC_L ? CAP : IVN;
   const int LNBI = STATIC_L ? cap_buckets(CAP) : P.iv_NB;
-  const int TS = STATIC_L ? CAP + kCapSpan : (RS > IVS ? RS : IVS);   // entries of the per-wave table
+  // the interval-only kernel's arithmetic layouts, run over the list of what the first launch left, also serve the
+  // headings outside the circular range (`quirky` below).  (An instantiation of its own: the same code inside the first
+  // launch's kernel cost every particle 36 instructions of 550 -- tests, branches and reloads of spilled registers.)
+  constexpr bool QK = IVONLY && LISTED && CAP > 0 && UNIF > 0;
+  const int TS = STATIC_L ? CAP + kCapSpan + (QK ? kSeamSlots : 0) : (RS > IVS ? RS : IVS);   // entries of the per-wave table
   unsigned long long* s_aux_all = s_rmin_all + (size_t)WPB * TS;
   unsigned int* s_walk_all = reinterpret_cast<unsigned int*>(s_aux_all + (size_t)((STAGE || PRODUCT) ? WPB * RS : 0));
   float* s_relx = reinterpret_cast<float*>(s_walk_all + (size_t)WPB * kWaveScratch);  // [G + B] extended angle table
@@ -314,6 +319,52 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
   unsigned short* s_ivlut = s_ivbeam + LB;                                                      // [iv_NB]
   unsigned int* s_ivends = reinterpret_cast<unsigned int*>(s_ivlut + ((LNBI + LB + 1) & ~1) - LB);   // [IVN], 4-byte aligned
 
+  // z*^2 as the FAST mixture wants it -- the largest float64 whose correctly rounded root does not exceed z*: the
+  // short-reading term applies where sqrt(r2) <= z* (range_sensor.py:47), decided below on r2 itself, and fl(z* z*) can
+  // fall an ulp short of the r2 whose root z* is (a particle that stands where the measurement was taken has z == z*
+  // in every beam).  The difference r2 - z*^2 that the Gaussian term takes from this entry is the same to 2e-16.
+  auto short_threshold = [](double zs) {
+    double c2 = zs * zs;
+    for (int it = 0; it < 4 && sqrt(__longlong_as_double(__double_as_longlong(c2) + 1)) <= zs; ++it) c2 = __longlong_as_double(__double_as_longlong(c2) + 1);
+    for (int it = 0; it < 4 && c2 > 0.0 && sqrt(c2) > zs; ++it) c2 = __longlong_as_double(__double_as_longlong(c2) - 1);
+    return c2;
+  };
+  constexpr bool ONE_PASS = IVONLY && CAP > 0 && UNIF > 0 && FAST && 64 * WPB >= CAP;
+  if constexpr (ONE_PASS) {
+    // the arithmetic layouts: a thread per table row, every load of the row asked for before the first is used (one
+    // trip to memory per block, not one per table: what a short list's launch spends its time on), and none of the
+    // tables that find an interval or a sector's start by lookup
+    const int k = threadIdx.x;
+    double ts = 0.0, zs = 0.0, el = 0.0;
+    unsigned int ends = 0u;
+    if (k < B) { ts = P.tab_sorted[k]; zs = P.zt[k]; el = P.etalam[k]; }
+    if (k < IVN) ends = P.iv_ends[k];
+    if (k < B) {
+      s_ts[k] = ts;
+      s_zt[k] = short_threshold(zs);
+      reinterpret_cast<float2*>(s_el)[k] = make_float2((float)zs, (float)(el * P.w_short));
+    }
+    if (k < IVN) s_ivends[k] = ends;
+  } else if constexpr (LISTED && FAST && !IVONLY) {
+    // the launch over a short list spends a good part of its time on these tables: every load of a row asked for
+    // before the first is used, rows of all tables side by side
+    const int rows = NXP > NB ? NXP : NB;   // (NXP > B)
+    for (int k = threadIdx.x; k < rows; k += blockDim.x) {
+      double ts = 0.0, zs = 0.0, el = 0.0;
+      unsigned short pk = 0, lk = 0;
+      float rx = 1.0e30f;                    // padding: beyond any window
+      if (k < B) { ts = P.tab_sorted[k]; pk = P.perm[k]; zs = P.zt[k]; el = P.etalam[k]; }
+      if (k < P.G + B) rx = P.relx[k];
+      if (k < NB) lk = P.lut[k];
+      if (k < B) {
+        s_ts[k] = ts; s_perm[k] = pk;
+        s_zt[k] = short_threshold(zs);
+        reinterpret_cast<float2*>(s_el)[k] = make_float2((float)zs, (float)(el * P.w_short));
+      }
+      if (k < NXP) s_relx[k] = rx;
+      if (k < NB) s_lut[k] = lk;
+    }
+  } else {
   for (int k = threadIdx.x; k < B; k += blockDim.x) {
     s_ts[k] = P.tab_sorted[k];
     if (!IVONLY) s_perm[k] = P.perm[k];
@@ -321,31 +372,25 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
   if (!STAGE)
     for (int k = threadIdx.x; k < NT; k += blockDim.x) {
       if constexpr (FAST) {
-        // z*^2 -- as the largest float64 whose correctly rounded root does not exceed z*: the short-reading term
-        // applies where sqrt(r2) <= z* (range_sensor.py:47), decided below on r2 itself, and fl(z* z*) can fall an ulp
-        // short of the r2 whose root z* is (a particle that stands where the measurement was taken has z == z* in
-        // every beam).  The difference r2 - z*^2 that the Gaussian term takes from this entry is the same to 2e-16.
         const double zs = P.zt[k];
-        double c2 = zs * zs;
-        for (int it = 0; it < 4 && sqrt(__longlong_as_double(__double_as_longlong(c2) + 1)) <= zs; ++it) c2 = __longlong_as_double(__double_as_longlong(c2) + 1);
-        for (int it = 0; it < 4 && c2 > 0.0 && sqrt(c2) > zs; ++it) c2 = __longlong_as_double(__double_as_longlong(c2) - 1);
-        s_zt[k] = c2;
+        s_zt[k] = short_threshold(zs);
         reinterpret_cast<float2*>(s_el)[k] = make_float2((float)zs, (float)(P.etalam[k] * P.w_short));
       } else {
         s_zt[k] = P.zt[k];
         s_el[k] = P.etalam[k];
       }
     }
+  }
   if (GRID) {
     for (int k = threadIdx.x; k < NE; k += blockDim.x) { s_cls[k] = P.g_cls[k]; s_member[k] = P.g_member[k]; }
     for (int k = threadIdx.x; k <= B; k += blockDim.x) s_first[k] = P.g_cls_first[k];
     for (int k = threadIdx.x; k < P.g_B0 + P.g_D; k += blockDim.x) s_ang[k] = P.g_ar[k];   // one array: beams, then headings
   }
-  if (!IVONLY) {
+  if (!IVONLY && !(LISTED && FAST)) {
     for (int k = threadIdx.x; k < NXP; k += blockDim.x) s_relx[k] = (k < P.G + B) ? P.relx[k] : 1.0e30f;  // padding: beyond any window
     for (int k = threadIdx.x; k < NB; k += blockDim.x) s_lut[k] = P.lut[k];
   }
-  if (IVK && IVN > 0) {
+  if (!ONE_PASS && IVK && IVN > 0) {
     for (int k = threadIdx.x; k <= IVN; k += blockDim.x) s_ivedge[k] = P.iv_edge[k];
     for (int k = threadIdx.x; k < B; k += blockDim.x) s_ivbeam[k] = P.iv_beam[k];
     for (int k = threadIdx.x; k < P.iv_NB; k += blockDim.x) s_ivlut[k] = P.iv_lut[k];
@@ -402,6 +447,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
   // ONE kind: with a store in flight every wait for one of those loads becomes a wait for all of them.
   constexpr int kOutBatch = 16;
   double* const outbuf = reinterpret_cast<double*>(ring);   // [kOutBatch]
+  unsigned int* const outidx = ring + 2 * kOutBatch;         // [kOutBatch] LISTED: whose result it is
   int out_slot = 0;                  // wave-uniform
   unsigned int out_mask = 0u;        // slots that hold a result (a particle left to the next launch has none)
   int64_t out_base = 0;              // the particle behind slot 0
@@ -413,7 +459,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
       KA ka = (KA)__builtin_amdgcn_kernarg_segment_ptr();
       asm volatile("" : "+s"(ka));
       double* const lo = ka->logw_out;
-      if (lane_ < kOutBatch && ((out_mask >> lane_) & 1u)) lo[out_base + (int64_t)lane_ * step_] = outbuf[lane_];
+      if (lane_ < kOutBatch && ((out_mask >> lane_) & 1u)) lo[LISTED ? (int64_t)outidx[lane_] : out_base + (int64_t)lane_ * step_] = outbuf[lane_];
       __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): no store is left outstanding
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
@@ -421,6 +467,10 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
     out_slot = 0;
   };
   unsigned long long* const imin = rmin;                               // the same array read as minima per sector interval
+  // QK: per beam near the seam of the bearings, what the cells at the seam gave it (see `quirky`)
+  unsigned long long* const smin = rmin + (STATIC_L ? CAP + kCapSpan : 0);
+  const float seam_wf = (float)((2.0 * P.half + 1e-4) / kTwoPi);     // QK: bearings this close to the seam (turns) are asked beam by beam
+  const int seam_wi = (int)ceil((2.0 * P.half + 1e-4) / kTwoPi * (double)P.iv_NE) + 2;   // ... in intervals, rounded up, and two for rounding
   const float iv_originf = (float)P.iv_origin, iv_inv_bwf = (float)((double)P.iv_NB / kTwoPi), iv_th_hif = (float)P.iv_th_hi, iv_th_midf = (float)P.iv_th_mid;
   const float iv_nearf = (float)kEdgeEps + (UNIF != 0 ? 4e-6f : 3e-6f);     // closer than this to a sector edge, float32 does not decide
   const float iv_near_uf = 0.5f - iv_nearf * (float)((double)P.iv_NE / kTwoPi);   // UNIF: the same band in interval widths, from the middle
@@ -512,7 +562,20 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
     const bool on_free = IVONLY ? (c_flags & 1u) != 0u : npm != 0;
     // headings for which the reference's predicate is the circular one take the interval path (wave-uniform); a
     // particle is done again entry by entry when a cell on a sector edge cannot be filed under intervals (see below)
-    const bool use_iv = IVONLY ? (c_flags & 2u) != 0u
+    // QK: a heading outside the range in which the reference's predicate is the circular one.  What differs there
+    // (mc_localization.py:143-149 recognises beam angle + heading - bearing within a turn of zero, no further):
+    //   a beam whose sector does not touch the seam of the bearings (bearing 0 = 2 pi) sees every cell of its sector
+    //   the same number of turns away, floor((beam angle + heading) / 2 pi): the beam keeps what the intervals hold if
+    //   that is -1, 0 or 1 and sees nothing otherwise;
+    //   a cell within two half-angles of the seam is not filed under an interval: it is parked, and asked with the
+    //   reference's own predicate for every beam whose sector may hold it; what it gives goes to a minimum per beam
+    //   (smin, for the kSeamSlots beams from seam_k0 on).  Sectors that touch the seam hold only such cells.
+    const bool quirky = QK && (c_flags & 4u) != 0u;
+    const float seam_w = quirky ? seam_wf : -1.0f;
+    int seam_k0 = 0, seam_turns = 0;      // quirky: the first beam with a slot in smin; the heading's whole turns ...
+    float seam_thf = 0.0f;                // ... and what is left of it
+    const float seam_lof = (float)P.half + 1e-5f, seam_hif = (float)(kTwoPi - P.half) - 1e-5f;
+    const bool use_iv = IVONLY ? (c_flags & (QK ? 6u : 2u)) != 0u
                                : (IVK && IVN > 0 && !entry_by_entry && fabsf((float)th - iv_th_midf) <= iv_th_hif);
     entry_by_entry = false;
     bool lane_redo = false;
@@ -611,6 +674,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
           if constexpr (UNIF != 0) {
             const bool inside = fabsf(uf - 0.5f) <= iv_near_uf;
             near_edge = !inside;                                                    // also NaN
+            if constexpr (QK) near_edge = near_edge || fabsf(aaf) < seam_w;         // at the seam of the bearings (never, unless `quirky`)
             at_lower = !(uf >= 0.5f);
           } else {
             at_lower = !(a - e0 >= iv_nearf);                                       // also NaN
@@ -623,7 +687,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
           else {
             // within rounding of edge E: parked, decided in float64 after the walk (rare; keeps the call out of this loop)
             COUNTL(2);
-            const unsigned int E = (unsigned int)(at_lower ? m : (m + 1 == IVN ? 0 : m + 1));
+            unsigned int E = (unsigned int)(at_lower ? m : (m + 1 == IVN ? 0 : m + 1));
+            if constexpr (QK) { if (fabsf(aaf) < seam_w) E = 0x80000000u | (unsigned int)m; }   // a cell at the seam: its interval
             const unsigned int pos = atomicAdd(edge_cnt, 1u);
             if (pos < (unsigned int)kEdgeQueue) edgeq[pos] = ((unsigned long long)E << 32) | e;
             else lane_redo = true;
@@ -767,16 +832,31 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
         // z_max, and without the entry-by-entry test a cell outside the disc costs less in a half-empty batch than the
         // compaction of every batch does (0.884 -> 0.856 ms at 2^20 x 180).
         // (a list is whole batches of 64, padded with a cell out of every pose's reach: no per-lane bounds)
-        const unsigned int n_list = (unsigned int)__builtin_amdgcn_readfirstlane((int)n_cells);
+        // (none for a particle that is left to the launch that follows)
+        const unsigned int n_list = use_iv ? (unsigned int)__builtin_amdgcn_readfirstlane((int)n_cells) : 0u;
         // (the loads go through the argument block's own pointer: one that has been made opaque is a generic pointer to
         // the compiler, and loads through those count against the LDS counter as well)
         // (the loads go through the argument block's own pointer: one that has been made opaque is a generic pointer to
         // the compiler, and loads through those count against the LDS counter as well)
+        if constexpr (QK) {
+          // the pass over what the first launch left is bound by the latency of a particle's chain of loads, not by
+          // issue: three batches in flight, asked for whether the list has them or not (the array is allocated that
+          // far beyond its last list; the count of outstanding loads is then the same on every path)
+          unsigned int e_b = P.nbr_cells[first_cell + 64 + lane], e_c = P.nbr_cells[first_cell + 128 + lane];
+          for (unsigned int sb = 0; sb < n_list; sb += 64) {
+            const unsigned int e = e_next;
+            COUNT(0);
+            e_next = e_b; e_b = e_c;
+            e_c = P.nbr_cells[first_cell + sb + 192 + lane];
+            match_cell(e, true, phase);
+          }
+        } else {
         for (unsigned int sb = 0; sb < n_list; sb += 64) {
           const unsigned int e = e_next;
           COUNT(0);
           if (sb + 64 < n_list) e_next = P.nbr_cells[first_cell + sb + 64 + lane];   // next batch in flight
           match_cell(e, true, phase);
+        }
         }
         n_cells = 0u;
         // Every batch has been consumed and the next record is needed now: an explicit vmcnt(0), on every path.  Without
@@ -844,6 +924,18 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
         // minima, and that one -- both refuse while interior sectors exist -- sends the particle through the
         // entry-by-entry test.
         // (most particles park nothing: a flag kept in a register spares them the read of the count and its wait)
+        if constexpr (QK) {
+          if (quirky) {
+            // the interval that holds the seam, and the first beam whose sector can reach a cell parked there
+            const int m_s = (int)(__builtin_amdgcn_fractf(-tho) * iv_nf);
+            seam_k0 = ((m_s - seam_wi - UNIF - 1 + P.iv_NE) / P.iv_stride) % B;
+            const double whole = rint(th * inv_two_pi);
+            seam_thf = (float)fma(-whole, kTwoPi, th);
+            seam_turns = (int)fmax(-1.0e6, fmin(1.0e6, whole));
+            smin[lane0] = r2max_bits;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          }
+        }
         const int nq = __ballot(lane_parked) != 0ull ? __builtin_amdgcn_readfirstlane((int)edge_cnt[0]) : 0;
         if constexpr (IVONLY) {
           if (nq > 0) {   // most particles park nothing: the count is cleared by the ones that did
@@ -859,11 +951,60 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
             const int col = (int)(e & 0xffffu), row = (int)(e >> 16);
             const double dx = (double)((float)col * P.res_xf) - x, dy = (double)((float)row * P.res_yf) - y;   // as in match_cell
             const unsigned long long r2bits = (unsigned long long)__double_as_longlong(FAST ? fma(dx, dx, dy * dy) : dx * dx + dy * dy);
-            const int left = E == 0 ? IVN - 1 : E - 1, right = E;
-            const unsigned int ends = s_ivends[E];
-            const double a_exact = exact_bearing(dy, dx);            // :133-135
+            const int left = E <= 0 ? IVN - 1 : E - 1, right = E < 0 ? 0 : E;
+            const unsigned int ends = s_ivends[right];
+            // a cell at the seam of the bearings (QK): every beam whose sector spans its interval or a neighbour of it
+            // (the float32 interval may be one off) is asked with the reference's predicate -- sectors that start at
+            // interval m + 1 down to m - UNIF.  Most of those beams hold the cell clearly inside or outside: the float32
+            // bearing (within 1e-6 rad) decides them, and the float64 arctangent is taken only where a sector edge -- or
+            // the seam itself, where the bearing jumps by a turn -- is within 1e-5 rad.
+            const bool at_seam = QK && E < 0;
+            unsigned int unsure = 0u;
+            const int seam_m = E & 0x7fffffff, seam_st = QK ? P.iv_stride : 1;
+            const int seam_kh = seam_st == 1 ? seam_m + 1 : (seam_m + 1) / seam_st;
+            auto seam_give = [&](int kk) {
+              int slot = kk - seam_k0;
+              slot += slot < 0 ? B : 0;
+              if (slot < kSeamSlots) atomicMin(&smin[slot], r2bits);
+              else lane_redo = true;                           // (cannot happen: the host has checked the span)
+            };
+            if constexpr (QK) {
+              if (at_seam) {
+                const float at = bearing_turns_f32((float)row * P.res_yf - yf, (float)col * P.res_xf - xf);
+                const double ar = (double)(at < 0.0f ? at + 1.0f : at) * kTwoPi;     // :133-135, approximately
+                const bool seam_sure = fabsf(at) > 4e-6f;
+                const float halff = (float)P.half, lof = (float)P.two_pi_lo, hif = (float)P.two_pi_hi;
+                int j = 0;
+                for (int k = seam_kh; k * seam_st >= seam_m - UNIF; --k, ++j) {
+                  const int kk = k < 0 ? k + B : (k >= B ? k - B : k);
+                  const float def = (float)fabs((s_ts[kk] + th) - ar);   // :143, :148 (where it matters, below 7: float32 holds it to 5e-7)
+                  const bool clear = fabsf(def - halff) > 1e-5f && fabsf(def - lof) > 1e-5f && fabsf(def - hif) > 1e-5f;
+                  if (!seam_sure || !clear) unsure |= 1u << j;
+                  else if (def <= halff || (def >= lof && def <= hif)) seam_give(kk);   // :149
+                }
+              }
+            }
+            double a_exact = 0.0;
+            if (!at_seam || unsure != 0u) a_exact = exact_bearing(dy, dx);            // :133-135
+            if constexpr (QK) {
+              if (at_seam && unsure != 0u) {
+                int j = 0;
+                for (int k = seam_kh; k * seam_st >= seam_m - UNIF; --k, ++j) {
+                  if (!((unsure >> j) & 1u)) continue;
+                  const int kk = k < 0 ? k + B : (k >= B ? k - B : k);
+                  const double de = fabs((s_ts[kk] + th) - a_exact);                  // :143, :148
+                  if ((de <= P.half) || (de >= P.two_pi_lo && de <= P.two_pi_hi)) seam_give(kk);   // :149
+                }
+              }
+            }
             auto refuses = [&](unsigned int k) {
-              const double de = fabs((s_ts[k] + th) - a_exact);      // :143, :148
+              const double beta = s_ts[k] + th;                      // :143
+              if constexpr (QK) {
+                // a beam two or more turns away sees nothing whatever is filed (see beam_r2bits): not a refusal that
+                // would send the particle through the entry-by-entry test
+                if (quirky && fabs(floor(beta * inv_two_pi)) > 1.0) return false;
+              }
+              const double de = fabs(beta - a_exact);                // :148
               return !((de <= P.half) || (de >= P.two_pi_lo && de <= P.two_pi_hi));   // :149
             };
             if constexpr (GRID) {
@@ -890,7 +1031,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
                 const unsigned int prev = s_ivends[left];
                 if ((prev >> 21) & 1u) give((prev >> 11) & 0x3ffu, false);
               }
-            } else {
+            } else if (!at_seam) {
             const bool no_end = ((ends >> 10) & 1u) && refuses(ends & 0x3ffu);
             const bool no_start = ((ends >> 21) & 1u) && refuses((ends >> 11) & 0x3ffu);
             if (!no_end) atomicMin(&imin[left], r2bits);
@@ -967,6 +1108,22 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
             best = lower(best, (uniform || j < cnt) ? v : best);
           }
           rb = (unsigned long long)__double_as_longlong(best);
+          if constexpr (QK) {
+            if (quirky) {
+              // (float32: the heading less its whole turns, taken once per particle; within 2e-6 rad, which the 1e-5 of
+              // margin covers -- a beam that is wrongly taken to touch the seam holds only cells that were parked)
+              const float bf = (float)s_ts[k] + seam_thf;                           // :143, less seam_turns turns
+              const float adj = floorf(bf * 0.15915494309189535f);
+              const float d = fmaf(-adj, 6.2831853071795865f, bf);                  // where the beam points, in [0, 2 pi)
+              const int turns = seam_turns + (int)adj;
+              const bool keeps = turns >= -1 && turns <= 1 && d > seam_lof && d < seam_hif;
+              int slot = k - seam_k0;
+              slot += slot < 0 ? B : 0;
+              const unsigned long long at_seam = slot < kSeamSlots ? smin[slot] : r2max_bits;
+              rb = keeps ? rb : r2max_bits;
+              rb = at_seam < rb ? at_seam : rb;
+            }
+          }
         }
       }
       return rb;
@@ -1117,7 +1274,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
       }
       const double lsd = wave_sum_fixed(l2s) * 0.6931471805599453;
       if constexpr (IVONLY) {
-        if (lane == 0) outbuf[out_slot] = on_free ? lsd : -INFINITY;
+        if (lane == 0) { outbuf[out_slot] = on_free ? lsd : -INFINITY; if constexpr (LISTED) outidx[out_slot] = (unsigned int)p; }
         out_mask |= 1u << out_slot;
         if (++out_slot == kOutBatch) flush_out(lane, step);
       } else if (lane == 0) logw_out[p] = on_free ? lsd : -INFINITY;
@@ -1232,7 +1389,7 @@ static size_t ray_lds_bytes(int B, int G, int NB, bool aux, int waves = kWavesPe
   const int NT = NE ? B0 : B;
   const int NXQ = NE ? std::max(NXP, iv_NE + iv_cmax) : NXP;                   // (histogram filter: class minima or interval minima, then per entry)
   const int RS = NXQ + NE + (NE ? B : 0);
-  const int TS = std::max(RS, iv_NE ? iv_NE + iv_cmax : 0);                    // per-wave table: per entry or per interval
+  const int TS = std::max(RS, iv_NE ? iv_NE + iv_cmax : 0) + (ivonly && cap > 0 ? kSeamSlots : 0);   // per-wave table: per entry or per interval (+ the beams at the seam)
   size_t s = (size_t)(B + 2 * NT) * sizeof(double);
   s += (size_t)waves * (TS + (aux ? RS : 0)) * sizeof(unsigned long long);
   s += (size_t)waves * kWaveScratch * sizeof(unsigned int);
@@ -1300,6 +1457,24 @@ static std::string ray_kernel_name(bool f32, bool stage, bool product, bool grid
          std::to_string(unif) + ">";
 }
 
+int ray_arith_span(const mclhip_ctx* c) {
+  if (!MCL_FAST_INTERVALS || c->iv_NE <= 0 || c->iv_cmax > kCapSpan) return 0;
+  if (!(c->iv_uniform && c->iv_cmin == c->iv_cmax && c->iv_stride > 0)) return 0;
+  auto fits = [&](int cc) { return c->B <= cc && c->iv_NE <= cc && c->iv_NB <= cap_buckets(cc); };
+  if (fits(192)) return c->iv_cmax == 5 ? 5 : 0;
+  if (fits(384) && 2 * kWavesPerBlock <= 16) return c->iv_cmax == 10 ? 10 : 0;
+  return 0;
+}
+
+bool ray_serves_every_heading(const mclhip_ctx* c) {
+  const int span = ray_arith_span(c);
+  if (span == 0 || !c->every_heading) return false;
+  // the beams that can receive a cell parked at the seam of the bearings are kSeamSlots at most (the kernel's seam_wi,
+  // seam_k0 and slots)
+  const int wi = (int)std::ceil((2.0 * c->half + 1e-4) / (2.0 * M_PI) * (double)c->iv_NE) + 2;
+  return (2 * wi + span + 2) / c->iv_stride + 2 <= kSeamSlots && c->iv_NE > wi + span + 2;
+}
+
 int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, const uint8_t* pm, int64_t n,
                    int dtype, double* w_out, double* logw_out, double* ranges_out, int32_t* hits_out,
                    const double* range_noise, double rn_sigma, uint64_t rn_seed, const QueryRecord* qrec) {
@@ -1318,10 +1493,17 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
   // kernel over that list.  Together 0.9x ms instead of 1.05 ms at 2^20 x 180.
   // (the interval-only kernel takes its particles from the records the motion kernel left)
   bool split = fast && P.iv_NE > 0 && c->redo_list && n <= c->redo_cap && pm != nullptr && qrec != nullptr && c->split_mode != 0;
+  // last time's left-over counts (a hint, see mclhip_ctx::redo_hint): of the first launch, and of the second pass
+  uint64_t left_a = 0, left_b = 0;
+  if (c->redo_hint)
+    for (int k = 0; k < kSubLists; ++k) {
+      left_a += reinterpret_cast<volatile uint32_t*>(c->redo_hint)[k];
+      left_b += reinterpret_cast<volatile uint32_t*>(c->redo_hint)[kSubLists + k];
+    }
+  const bool every = split && ray_serves_every_heading(c) && c->redo_list2 != nullptr &&
+                     (c->every_heading == 1 || (c->every_heading < 0 && left_a * 16 > (uint64_t)n && left_a * 2 < (uint64_t)n));
   if (split && c->split_mode < 0 && c->redo_hint) {
-    // last time's left-over count (a hint, see mclhip_ctx::redo_hint)
-    uint64_t left = 0;
-    for (int k = 0; k < kSubLists; ++k) left += reinterpret_cast<volatile uint32_t*>(c->redo_hint)[k];
+    const uint64_t left = every ? left_b : left_a;
     if (left * 4 > (uint64_t)n && (++c->split_skipped % 8) != 0) split = false;
   }
   // Wavefronts per block.  The block-wide tables grow with the beam count; when they keep a compute unit from holding
@@ -1381,14 +1563,14 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
       if ((int64_t)P.sub_cap * kSubLists > c->redo_cap + mclhip_ctx::kRedoSlack) return fail(c, MCLHIP_E_LIMIT, "left-over list too small");
       const size_t lds_b = ray_lds_bytes(P.B, P.G, P.NB, false, kWavesPerBlock, 0, 0, 0, 0, 0);   // the second launch's
       if (lds_b > 160 * 1024) return fail(c, MCLHIP_E_LIMIT, "beam table does not fit the kernel's LDS budget");
-      MCL_HIP(c, hipMemsetAsync(c->redo_count, 0, kSubLists * sizeof(uint32_t), c->stream));
+      MCL_HIP(c, hipMemsetAsync(c->redo_count, 0, 2 * kSubLists * sizeof(uint32_t), c->stream));   // (both lists' counts)
       P.redo_list = c->redo_list; P.redo_count = c->redo_count;
       timing_begin(c, 0);
-      const bool even = c->iv_uniform, same = c->iv_cmin == c->iv_cmax;     // equally wide intervals; as many per sector
-      const bool arith = c->iv_stride > 0;                                   // sectors start at k * stride: the UNIF > 0 variants
-      if (cap == 192 && even && same && arith && c->iv_cmax == 5) MCL_RAY_U(float, false, false, false, true, kWavesPerBlock, true, false, 192, 5);
+      const bool even = c->iv_uniform;                                       // equally wide intervals
+      const int arith = ray_arith_span(c);                                   // ... as many per sector, sectors start at k * stride: the UNIF > 0 variants
+      if (cap == 192 && arith == 5) MCL_RAY_U(float, false, false, false, true, kWavesPerBlock, true, false, 192, 5);
       else if (cap == 192 && even) MCL_RAY_U(float, false, false, false, true, kWavesPerBlock, true, false, 192, -1);
-      else if (cap == 384 && even && same && arith && c->iv_cmax == 10) MCL_RAY_U(float, false, false, false, true, 2 * kWavesPerBlock, true, false, 384, 10);
+      else if (cap == 384 && arith == 10) MCL_RAY_U(float, false, false, false, true, 2 * kWavesPerBlock, true, false, 384, 10);
       else if (cap == 384 && even) MCL_RAY_U(float, false, false, false, true, 2 * kWavesPerBlock, true, false, 384, -1);
       else if (cap == 192) MCL_RAY_W(float, false, false, false, true, kWavesPerBlock, true, false, 192);
       else if (cap == 384) MCL_RAY_W(float, false, false, false, true, 2 * kWavesPerBlock, true, false, 384);
@@ -1400,12 +1582,38 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
       // what is left over, entry by entry (no interval tables; the list's length is known to the device only: the
       // grid is sized for every particle and the blocks beyond the list leave at once -- a short list is bound by
       // the latency of one particle per wave, so it wants many waves rather than long strides)
-      P.redo_list = nullptr; P.redo_count = nullptr; P.list = c->redo_list; P.list_count = c->redo_count;
+      int64_t blocks_q = (n + wpb - 1) / wpb;
+      const int64_t cap_q = 3584 * kWavesPerBlock / wpb;                    // (as below)
+      if (blocks_q > cap_q) blocks_q = cap_q;
+      blocks_q = (blocks_q + kSubLists - 1) / kSubLists * kSubLists;
+      if (every) {
+        // first the arithmetic interval kernel once more, over the list: it serves the headings outside the circular
+        // range as well (the records say which particles those are) and files what is then left -- particles with a
+        // cell on a sector edge that intervals cannot take, headings that are not finite -- in a second list
+        P.list = c->redo_list; P.list_count = c->redo_count;
+        P.redo_list = c->redo_list2; P.redo_count = c->redo_count + kSubLists;
+        const dim3 grid_q((unsigned)blocks_q);
+#define MCL_RAY_Q(WW, CC, UU)                                                                                          \
+  do {                                                                                                               \
+    auto kern = raycast_kernel<float, false, false, false, WW, false, true, true, true, CC, UU>;                      \
+    if (lds > 48 * 1024)                                                                                             \
+      MCL_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                     (int)lds));                                                                     \
+    hipLaunchKernelGGL(kern, grid_q, block, lds, c->stream, P, (const float*)x, (const float*)y, (const float*)th,   \
+                       pm, n, w_out, logw_out, ranges_out, hits_out, qrec);                                          \
+  } while (0)
+        if (cap == 192) MCL_RAY_Q(kWavesPerBlock, 192, 5); else MCL_RAY_Q(2 * kWavesPerBlock, 384, 10);
+#undef MCL_RAY_Q
+        MCL_HIP(c, hipGetLastError());
+      }
+      P.redo_list = nullptr; P.redo_count = nullptr;
+      P.list = every ? c->redo_list2 : c->redo_list; P.list_count = every ? c->redo_count + kSubLists : c->redo_count;
       P.iv_NE = 0; P.iv_cmax = 0;
       int64_t blocks_b = (n + kWavesPerBlock - 1) / kWavesPerBlock;
       // (two rounds of the blocks a chip holds: measured at 2^20 particles with 33000 left over, 16384 blocks 0.070 ms,
       // 7168 0.067, 3584 0.063, 1792 0.062, 896 0.083)
-      if (blocks_b > 3584) blocks_b = 3584;
+      // (after the arithmetic kernel's second pass the list holds a handful: a small grid, whose fixed cost is small)
+      if (blocks_b > (every ? 512 : 3584)) blocks_b = every ? 512 : 3584;
       blocks_b = (blocks_b + kSubLists - 1) / kSubLists * kSubLists;      // the same number of blocks behind every list
       {
         auto kern = raycast_kernel<float, false, false, false, kWavesPerBlock, false, true, false, true>;
@@ -1417,7 +1625,8 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
       }
       timing_end(c);
       if (c->redo_hint)
-        MCL_HIP(c, hipMemcpyAsync(c->redo_hint, c->redo_count, kSubLists * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        MCL_HIP(c, hipMemcpyAsync(c->redo_hint, c->redo_count, 2 * kSubLists * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+      c->every_last = every;
     }
     else if (fast && wpb != kWavesPerBlock) MCL_RAY_W(float, false, false, false, true, 2 * kWavesPerBlock, false, false, 0);
     else if (fast) MCL_RAY_F(float, false, false, false, true);

@@ -266,16 +266,22 @@ def test_f32_state_mode(name):
     assert np.max(np.abs(logw3[fin] - lwn[fin]) / np.maximum(1.0, np.abs(lwn[fin]))) < 1e-5
 
 
+@pytest.mark.parametrize("every", ["0", "1"])
 @pytest.mark.parametrize("beams", ["even180", "even360", "reference13", "uneven", "wide_repeated", "narrow", "single"])
-def test_sector_intervals_against_the_oracle(beams):
+def test_sector_intervals_against_the_oracle(beams, every, monkeypatch):
     """The float32 instantiation files a cell under the sector interval its bearing falls in (one minimum per interval,
     a beam's range = the smallest of the intervals its sector spans) when no beam angle + heading leaves the range in
     which the reference recognises a turn (mc_localization.py:148-149); other headings go beam by beam, bearings within
     rounding of a sector edge are decided in float64.  Headings on both sides of the two
     limits, negative ones and ones past a full turn, evenly and unevenly spaced beam sets (overlapping sectors, disjoint
-    sectors, sectors that share an edge): log-weights against the oracle's, which follows mc_localization.py:116-171."""
+    sectors, sectors that share an edge): log-weights against the oracle's, which follows mc_localization.py:116-171.
+    every = "1": evenly spaced beams whose spacing divides the sector (even180, even360) have the headings outside that
+    range served by a second pass of the interval kernel (cells at the seam of the bearings asked beam by beam, beams
+    two or more turns away seeing nothing) instead of entry by entry; the other tables do not have that pass."""
     from slam_amd import workload as W
     L = _lib()
+    monkeypatch.setenv("MCLHIP_EVERY_HEADING", every)       # (read when a context is created)
+    monkeypatch.setenv("MCLHIP_SPLIT", "1")
     grid = W.synthetic_map(256)
     if beams == "even180":
         angles = W.beam_angles(180)
@@ -328,6 +334,11 @@ def test_sector_intervals_against_the_oracle(beams):
     tie = np.zeros(M, bool); tie[600:700] = True
     assert err[~tie[fin]].max() < 1e-5, (beams, err[~tie[fin]].max())
     assert np.mean(err[tie[fin]] < 1e-5) > 0.9
+    first_left, then_left = ctx.timing_get(7)[0], ctx.timing_get(6)[0]
+    if beams in ("even180", "even360"):
+        outside = int(np.sum((Xd[:, 2] > lim_hi) | (Xd[:, 2] < lim_lo)))
+        assert first_left >= outside - 80                      # (within 1e-3 of a limit the kernel may draw the line either way)
+        assert (then_left < first_left // 4) if every == "1" else (then_left == first_left)
     ctx.close()
 
 
@@ -649,8 +660,10 @@ def test_fused_step_equals_the_separate_calls(dtype, mode):
 def test_one_kernel_and_two_launch_sector_query_agree_bit_for_bit(monkeypatch):
     """The float32 throughput path runs the sector query as two launches (interval-only kernel + the general kernel over
     what it leaves) or, when most of the cloud lies outside the interval path's heading range, as the one kernel that
-    holds both paths (MCLHIP_SPLIT = 1 / 0 force either; read when a context is created).  Which one runs is a matter
-    of speed only: the log-weights are the same bits."""
+    holds both paths (MCLHIP_SPLIT = 1 / 0 force either; read when a context is created); between the two launches the
+    interval kernel may make a second pass, over the list, that serves the headings outside the range as well
+    (MCLHIP_EVERY_HEADING = 1 / 0; by itself when a sixteenth to half of the cloud was left).  Which of these run is a
+    matter of speed only: the log-weights are the same bits."""
     from slam_amd import workload as W
     L = _lib()
     grid = W.synthetic_map(256)
@@ -664,11 +677,13 @@ def test_one_kernel_and_two_launch_sector_query_agree_bit_for_bit(monkeypatch):
     w4 = np.array([0.97, 0.005, 0.020, 0.005]); w4 /= w4.sum()
     zero = np.zeros((M, 3, 12), np.int16)
     got = {}
-    for mode in ("0", "1", "auto"):
+    for mode in ("0", "1", "1+every", "auto"):
+        monkeypatch.delenv("MCLHIP_EVERY_HEADING", raising=False)
         if mode == "auto":
             monkeypatch.delenv("MCLHIP_SPLIT", raising=False)
         else:
-            monkeypatch.setenv("MCLHIP_SPLIT", mode)
+            monkeypatch.setenv("MCLHIP_SPLIT", mode[0])
+            monkeypatch.setenv("MCLHIP_EVERY_HEADING", "1" if mode.endswith("every") else "0")
         ctx = L.Context(0, L.F32)
         ctx.set_map(grid, W.RES, W.RES)
         ctx.set_sensor(W.beam_angles(180), W.Z_MAX, 0.15, 1.0, w4, 5 * np.pi / 180.0)
@@ -680,6 +695,7 @@ def test_one_kernel_and_two_launch_sector_query_agree_bit_for_bit(monkeypatch):
         ctx.close()
     assert np.isfinite(got["0"]).mean() > 0.8
     assert np.array_equal(got["0"], got["1"], equal_nan=True) and np.array_equal(got["0"], got["auto"], equal_nan=True)
+    assert np.array_equal(got["0"], got["1+every"], equal_nan=True)
 
 
 @pytest.mark.parametrize("seed", range(48))
