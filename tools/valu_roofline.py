@@ -23,7 +23,7 @@ profile whose sources are not the ones in the tree (`stale`).  --workload: what 
 
 Two figures beside the issue fraction say how much of the issued work is needed at all:
   * lane utilisation: of the 64 lanes of a vector instruction, how many were switched on, on average
-    (SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU x 4), when the pass has the counter; and from the counting
+    (SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU), when the pass has the counter; and from the counting
     build of the kernel: obstacle cells within z_max per fetched lane-slot of the cell loop);
   * the algorithmic instruction floor: the fewest vector wave-instructions a particle needs on this hardware if
     every lane of every instruction did needed work --
@@ -191,8 +191,8 @@ def main():
         res["workload"] = json.loads(" ".join(opt["workload"]))
     # lane utilisation by the hardware's count, when the passes have it
     if ctr.get("SQ_THREAD_CYCLES_VALU") and ctr.get("SQ_ACTIVE_INST_VALU"):
-        res["lane_utilisation_hw"] = ctr["SQ_THREAD_CYCLES_VALU"] / (64.0 * 4.0 * ctr["SQ_ACTIVE_INST_VALU"])
-        res["lane_utilisation_hw_is"] = "SQ_THREAD_CYCLES_VALU / (64 x 4 x SQ_ACTIVE_INST_VALU): lanes switched on per vector instruction"
+        res["lane_utilisation_hw"] = ctr["SQ_THREAD_CYCLES_VALU"] / (64.0 * ctr["SQ_ACTIVE_INST_VALU"])
+        res["lane_utilisation_hw_is"] = "SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU), both counted per wave in quad-cycles: lanes switched on per vector instruction (lanes that compute for a cell outside the disc are on: what they do is not needed, see the cell loop's figure)"
     if "counts" in opt:
         res["cell_loop"] = json.load(open(opt["counts"][0]))
     if "work" in opt:
