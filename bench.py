@@ -464,7 +464,12 @@ def main():
             "roofline": roofline(a, M, B, ray_ms, n_ray, copy_gbs, kernel_name),
             "exchange": ({"rows_per_step_max_over_ranks": ex_rows,
                           "bytes_between_ranks_per_step_max_over_ranks": 48.0 * ex_off,
-                          "host_reads_per_step": 1 if filt.device_path else "host-combined: about 13",
+                          "host_reads_per_step": (("1, after the step's last kernel has been enqueued (row blocks of %d per pair of ranks)"
+                                                   % filt.fixed_rows) if getattr(filt, "fixed_rows", 0) else 1)
+                          if filt.device_path else "host-combined: about 13",
+                          "steps_finished_with_exact_counts": getattr(filt, "exact_exchanges", None),
+                          "host_ms_per_step": ({k: 1e3 * v / max(getattr(filt, "steps_done", 0), 1)
+                                                for k, v in getattr(filt, "clock", {}).items()} or None),
                           "note": "only rows that some position draws travel (48 B each)"}
                          if filt.collective else None),
             "kernel_ms": {"raycast": ray_ms, "raycast_leftover_launch": (ms_left / n_left) if n_left else None,

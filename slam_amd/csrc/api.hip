@@ -401,7 +401,7 @@ void mclhip_destroy(mclhip_ctx* c) {
                   c->sx, c->sy, c->sth, c->sw, c->chunk_sums, c->scal, c->cdf_approx, c->cdf_exact, c->kscan,
                   c->fscan, c->blk_a, c->blk_b, c->irr, c->bases, c->idx, c->noise, c->counters, c->range_noise, c->inj_rows, c->stamps,
                   c->inj_poses, c->g_records, c->g_bases, c->gl_mask, c->gl_x, c->gl_y, c->gl_th, c->gl_cell, c->gl_pk, c->gl_pk_pred, c->gl_K, c->gl_part, c->gl_cls, c->gl_cls_first, c->gl_member, c->gl_mbeta, c->gl_zt, c->gl_el, c->gl_zm,
-                  c->rows_send, c->rows_recv, c->small_d, c->small_i, c->sel};
+                  c->rows_send, c->rows_recv, c->rows_self, c->small_d, c->small_i, c->sel};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (c->zpin) (void)hipHostFree(c->zpin);
@@ -1321,6 +1321,42 @@ int mclhip_dshard_unpack_resample(mclhip_ctx* c, const void* d_rows, int64_t L, 
   span_begin(c, c->spans, 2);
   MCL_TRY(launch_unpack_drawn(c, (const double*)d_rows, L, r, false));
   span_end(c, c->spans);
+  return MCLHIP_OK;
+}
+
+int mclhip_dshard_pack_fixed(mclhip_ctx* c, int world, int rank, int64_t cap_rows, void* d_blocks) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, false, false, true));
+  if (!d_blocks || world < 1 || world > 64 || rank < 0 || rank >= world || cap_rows < 1)
+    return fail(c, MCLHIP_E_ARG, "d_blocks NULL, world outside 1..64, rank outside the world or cap_rows < 1");
+  if (c->M + 64 > c->rows_self_cap) {
+    MCL_HIP(c, hipStreamSynchronize(c->stream));
+    MCL_TRY(dev_alloc(c, &c->rows_self, (size_t)(c->M + 64) * 6 * sizeof(double)));
+    c->rows_self_cap = c->M + 64;
+  }
+  span_begin(c, c->spans, 2);
+  MCL_TRY(launch_pack_fixed(c, world, rank, cap_rows, (double*)d_blocks, (double*)c->rows_self));
+  span_end(c, c->spans);
+  return MCLHIP_OK;
+}
+
+int mclhip_dshard_unpack_fixed(mclhip_ctx* c, const void* d_blocks, const int64_t* d_all_counts, int world, int rank,
+                               int64_t cap_rows, double r, int64_t* d_flag_out) {
+  MCL_TRY(use(c));
+  MCL_TRY(need(c, false, false, true));
+  if (!d_blocks || !d_all_counts || !d_flag_out || world < 1 || world > 64 || rank < 0 || rank >= world || cap_rows < 1)
+    return fail(c, MCLHIP_E_ARG, "NULL argument, world outside 1..64, rank outside the world or cap_rows < 1");
+  if (!c->rows_self) return fail(c, MCLHIP_E_STATE, "mclhip_dshard_pack_fixed comes first");
+  span_begin(c, c->spans, 2);
+  MCL_TRY(launch_unpack_fixed(c, (const double*)d_blocks, (const double*)c->rows_self, d_all_counts, world, rank, cap_rows, r,
+                              d_flag_out));
+  span_end(c, c->spans);
+  return MCLHIP_OK;
+}
+
+int mclhip_dshard_unpack_undo(mclhip_ctx* c) {
+  MCL_TRY(use(c));
+  c->cur = 1 - c->cur;
   return MCLHIP_OK;
 }
 

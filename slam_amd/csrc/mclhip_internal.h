@@ -260,6 +260,7 @@ struct mclhip_ctx {
   void* g_bases = nullptr;
   void* rows_send = nullptr; int64_t rows_send_cap = 0;   // packed rows handed to / received from the exchange
   void* rows_recv = nullptr; int64_t rows_recv_cap = 0;
+  void* rows_self = nullptr; int64_t rows_self_cap = 0;   // the fixed-block exchange: the rows a rank draws from itself
   int64_t* sel = nullptr; int64_t sel_cap = 0;            // local row behind every place of the send buffer (drawn-row exchange)
   int64_t drawn_total = 0;                                // rows the last plan sends in all
   double* small_d = nullptr; int64_t* small_i = nullptr;  // [1024] staging for boundary queries
@@ -370,6 +371,9 @@ int launch_count_below(mclhip_ctx* c, const double* d_U, int nu, int64_t* d_coun
 int launch_plan_drawn(mclhip_ctx* c, const ShardLayout& lay, double r, int64_t* d_counts, const unsigned long long* meta);
 int launch_pack_drawn(mclhip_ctx* c, int world, double* d_dst, int64_t* d_sel);
 int launch_unpack_drawn(mclhip_ctx* c, const double* d_rows, int64_t L, double r, bool keep_pos);
+int launch_pack_fixed(mclhip_ctx* c, int world, int rank, int64_t cap, double* d_dst, double* d_self);
+int launch_unpack_fixed(mclhip_ctx* c, const double* d_recv, const double* d_self, const int64_t* d_all_counts, int world,
+                        int rank, int64_t cap, double r, int64_t* d_flag_out);
 int launch_pack_rows(mclhip_ctx* c, int64_t lo, int64_t hi, double* d_dst);
 int launch_unpack_resample(mclhip_ctx* c, const double* d_rows, int64_t L, int64_t first_index, int64_t m_total,
                            double r, int64_t row0_global);

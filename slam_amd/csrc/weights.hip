@@ -1135,6 +1135,151 @@ __global__ __launch_bounds__(256) void unpack_drawn_kernel(const double* __restr
   w2[j] = s[3];
 }
 
+// ---- the same exchange without a host read: every pair of ranks exchanges a block of `cap` rows, whatever it holds.
+// The rows a rank draws from itself -- all of them when the weights are flat -- never enter the exchange: they are
+// packed into a buffer of the context's own.  What a block holds is known from the gathered counts, on the device;
+// whether every block was large enough is known there too, and the host looks at that flag only after the step has
+// been enqueued to its end (nothing is resampled when it is set: the step is then finished with exact counts).
+template <typename T>
+__global__ __launch_bounds__(256) void pack_fixed_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ th,
+                                                         const double* __restrict__ w, const double* __restrict__ cdf,
+                                                         const int64_t* __restrict__ G, const unsigned int* __restrict__ S,
+                                                         int64_t n, int64_t first_index, int world, int rank, int64_t cap,
+                                                         const int64_t* __restrict__ slices, double* __restrict__ dst,
+                                                         double* __restrict__ self_dst) {
+  __shared__ int64_t s_sl[4 * 64];
+  for (int k = threadIdx.x; k < 4 * world; k += blockDim.x) s_sl[k] = slices[k];
+  __syncthreads();
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  if (!(j == 0 || G[j] > G[j - 1])) return;
+  const int64_t sj = (int64_t)S[j];
+  for (int d = 0; d < world; ++d) {
+    const int64_t jl = s_sl[4 * d], jh = s_sl[4 * d + 1];
+    if (s_sl[4 * d + 2] == 0 || j < jl || j > jh) continue;
+    const int64_t local = (sj - (jl > 0 ? (int64_t)S[jl - 1] : 0)) - 1;     // place among the rows for rank d
+    double* row;
+    if (d == rank) row = self_dst + local * 6;
+    else if (local < cap) row = dst + ((int64_t)d * cap + local) * 6;
+    else continue;                                                          // does not fit its block: the flag says so
+    row[0] = (double)x[j];
+    row[1] = (double)y[j];
+    row[2] = (double)th[j];
+    row[3] = w[j];
+    row[4] = cdf[j];
+    row[5] = __longlong_as_double((long long)(first_index + j));
+  }
+}
+
+// meta[0] = 0 fine, 1 a rank's record merge overflowed (nothing was planned), 2 some pair's rows exceed `cap`;
+// meta[1] = rows this rank receives; meta[2 + s] = how many of them come before source s's.  The flag is the same on
+// every rank: it is formed from the whole gathered matrix.
+__global__ void exchange_meta_kernel(const int64_t* __restrict__ all_counts, int world, int rank, int64_t cap,
+                                     int64_t* __restrict__ meta, int64_t* __restrict__ flag_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int64_t flag = 0;
+  for (int s = 0; s < world; ++s) {
+    if (all_counts[(size_t)s * (world + 1) + world] != 0) flag = 1;
+    for (int d = 0; d < world && flag != 1; ++d)
+      if (s != d && all_counts[(size_t)s * (world + 1) + d] > cap) flag = 2;
+  }
+  int64_t off = 0;
+  for (int s = 0; s < world; ++s) {
+    meta[2 + s] = off;
+    off += all_counts[(size_t)s * (world + 1) + rank];
+  }
+  meta[2 + world] = off;
+  meta[1] = off;
+  meta[0] = flag;
+  flag_out[0] = flag;
+}
+
+// unpack_drawn_kernel over rows that stand in one block per source (the rank's own in its own buffer)
+template <typename T>
+__global__ __launch_bounds__(256) void unpack_fixed_kernel(const double* __restrict__ recv, const double* __restrict__ self_rows,
+                                                           const int64_t* __restrict__ meta, int world, int rank, int64_t cap,
+                                                           int64_t first_index, int64_t m_total, int64_t n, double r,
+                                                           T* __restrict__ x2, T* __restrict__ y2, T* __restrict__ th2,
+                                                           double* __restrict__ w2, int64_t* __restrict__ idx) {
+  __shared__ int64_t s_off[66];
+  for (int k = threadIdx.x; k < world + 1; k += blockDim.x) s_off[k] = meta[2 + k];
+  const int64_t flag = meta[0];
+  __syncthreads();
+  if (flag != 0) return;
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const double U = position_u(first_index + j, m_total, r);
+  auto block_of = [&](int s) { return s == rank ? self_rows : recv + (int64_t)s * cap * 6; };
+  // the source whose rows hold the first running sum that is not below U: sources ascend, so it is the first one whose
+  // last row qualifies; if there is none, the last row of all (the clamp of the single-GPU walk)
+  int src = -1, last_src = -1;
+  for (int s = 0; s < world; ++s) {
+    const int64_t len = s_off[s + 1] - s_off[s];
+    if (len <= 0) continue;
+    last_src = s;
+    if (!(U > block_of(s)[(len - 1) * 6 + 4])) { src = s; break; }
+  }
+  if (last_src < 0) return;                                  // (no rows at all: cannot happen, every position has an ancestor)
+  const double* rows;
+  int64_t lo = 0;
+  if (src < 0) {
+    rows = block_of(last_src);
+    lo = s_off[last_src + 1] - s_off[last_src] - 1;
+  } else {
+    rows = block_of(src);
+    int64_t hi = s_off[src + 1] - s_off[src];
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (U > rows[mid * 6 + 4]) lo = mid + 1; else hi = mid;
+    }
+  }
+  const double* sr = rows + lo * 6;
+  idx[j] = (int64_t)__double_as_longlong(sr[5]);
+  x2[j] = (T)sr[0];
+  y2[j] = (T)sr[1];
+  th2[j] = (T)sr[2];
+  w2[j] = sr[3];
+}
+
+int launch_pack_fixed(mclhip_ctx* c, int world, int rank, int64_t cap, double* d_dst, double* d_self) {
+  const int64_t n = c->M;
+  const int a = c->cur;
+  const unsigned g = (unsigned)((n + 255) / 256);
+  const int64_t* G = reinterpret_cast<const int64_t*>(c->kscan);
+  const int64_t* slices = c->small_i + 8;
+  if (c->dtype == MCLHIP_F32)
+    hipLaunchKernelGGL(pack_fixed_kernel<float>, dim3(g), dim3(256), 0, c->stream, (const float*)c->px[a], (const float*)c->py[a],
+                       (const float*)c->pth[a], (const double*)c->w[a], (const double*)c->cdf_exact, G, (const unsigned int*)c->fscan,
+                       n, c->first_index, world, rank, cap, slices, d_dst, d_self);
+  else
+    hipLaunchKernelGGL(pack_fixed_kernel<double>, dim3(g), dim3(256), 0, c->stream, (const double*)c->px[a], (const double*)c->py[a],
+                       (const double*)c->pth[a], (const double*)c->w[a], (const double*)c->cdf_exact, G, (const unsigned int*)c->fscan,
+                       n, c->first_index, world, rank, cap, slices, d_dst, d_self);
+  MCL_HIP(c, hipGetLastError());
+  return MCLHIP_OK;
+}
+
+// (the arrays are swapped here, on the host, whether or not the kernel resamples: see mclhip_dshard_unpack_fixed)
+int launch_unpack_fixed(mclhip_ctx* c, const double* d_recv, const double* d_self, const int64_t* d_all_counts, int world,
+                        int rank, int64_t cap, double r, int64_t* d_flag_out) {
+  const int64_t n = c->M;
+  const int b = 1 - c->cur;
+  const unsigned g = (unsigned)((n + 255) / 256);
+  int64_t* meta = c->small_i + 8 + 4 * 64 + 128;               // behind the merge's words, the slices and the host path's counts
+  hipLaunchKernelGGL(exchange_meta_kernel, dim3(1), dim3(64), 0, c->stream, d_all_counts, world, rank, cap, meta, d_flag_out);
+  if (c->dtype == MCLHIP_F32)
+    hipLaunchKernelGGL(unpack_fixed_kernel<float>, dim3(g), dim3(256), 0, c->stream, d_recv, d_self, (const int64_t*)meta, world,
+                       rank, cap, c->first_index, c->m_total, n, r, (float*)c->px[b], (float*)c->py[b], (float*)c->pth[b],
+                       c->w[b], c->idx);
+  else
+    hipLaunchKernelGGL(unpack_fixed_kernel<double>, dim3(g), dim3(256), 0, c->stream, d_recv, d_self, (const int64_t*)meta, world,
+                       rank, cap, c->first_index, c->m_total, n, r, (double*)c->px[b], (double*)c->py[b], (double*)c->pth[b],
+                       c->w[b], c->idx);
+  MCL_HIP(c, hipGetLastError());
+  c->cur = b;
+  return MCLHIP_OK;
+}
+
 int launch_dshard_scan(mclhip_ctx* c, const double* d_all_chunks, const ShardLayout& lay, void* d_rec_out, int cap) {
   hipLaunchKernelGGL(shard_totals_kernel, dim3(1), dim3(64), 0, c->stream, d_all_chunks, lay, c->scal);
   MCL_TRY_W(launch_shard_scan(c, 0.0, 0.0, c->first_index, c->scal + 5));

@@ -155,11 +155,14 @@ def sequential_sum(values):
     return float(t)
 
 
-def drive_exchanges(gen, torch, dist, stream):
+def drive_exchanges(gen, torch, dist, stream, clock=None):
     """Serve the exchanges a device-step generator asks for with torch.distributed, on the step's stream.  Under RCCL
     the collectives read and write the device tensors; under gloo (ranks that share one GPU, in tests) the same calls
-    run on host copies."""
+    run on host copies.  clock: a dict that receives the host's time per step -- "enqueue_s" up to the step's one wait,
+    "wait_s" in it -- for reports."""
+    import time
     staged = dist.get_backend() != "nccl"
+    t_begin = time.perf_counter()
 
     def gather(out, inp):
         if staged:
@@ -197,6 +200,20 @@ def drive_exchanges(gen, torch, dist, stream):
                         val[:n_out].copy_(host)
                     else:
                         dist.all_to_all_single(val[:n_out], send[:n_in], [int(c) for c in rc], [int(c) for c in sc])
+                elif op == "all_to_all_fixed":
+                    recv, send = req[1], req[2]            # equal blocks, one per rank
+                    if staged:
+                        host = torch.empty(recv.shape, dtype=recv.dtype)
+                        dist.all_to_all_single(host, send.cpu())
+                        recv.copy_(host)
+                    else:
+                        dist.all_to_all_single(recv, send)
+                elif op == "read_late":
+                    t_wait = time.perf_counter()
+                    val = req[1].cpu().numpy()             # everything of the step is enqueued: the one wait, at its end
+                    if clock is not None:
+                        clock["enqueue_s"] = clock.get("enqueue_s", 0.0) + (t_wait - t_begin)
+                        clock["wait_s"] = clock.get("wait_s", 0.0) + (time.perf_counter() - t_wait)
                 req = gen.send(val)
         except StopIteration as done:
             return done.value
@@ -206,6 +223,12 @@ class ShardedFilter:
     """Drives one MCL update per call over `world` ranks."""
 
     RECORD_CAP = 256     # irregular records per rank that fit the fixed-size exchange of the device-driven step
+    # Rows per pair of ranks in the device-driven step's row exchange (0: exact counts, read by the host in the middle
+    # of the step).  With blocks of a fixed size nothing the host needs to know stands between the first kernel of a
+    # step and its last: the host enqueues the whole step while the sector query runs, and looks at one flag at the
+    # end.  Rows a rank draws from itself do not count (they never enter the exchange); between two ranks a handful
+    # of rows is the rule, a pair that has more finishes that step with exact counts.
+    FIXED_ROWS = 2048
 
     def __init__(self, ctx_or_backend, dist, rank, world, m_local, weight_mode=_lib.W_LOG, force_collectives=False,
                  device_path=None):
@@ -267,7 +290,15 @@ class ShardedFilter:
         self.t_rec = torch.zeros(rb, dtype=torch.int64, device=dev)
         self.t_all_rec = torch.zeros(W * rb, dtype=torch.int64, device=dev)
         self.t_counts = torch.zeros(W + 1, dtype=torch.int64, device=dev)            # rows for every rank + overflow flag
-        self.t_all_counts = torch.zeros(W * (W + 1), dtype=torch.int64, device=dev)
+        self.t_late = torch.zeros(W * (W + 1) + 1, dtype=torch.int64, device=dev)    # what the host reads: the gathered counts ...
+        self.t_all_counts = self.t_late[:W * (W + 1)]
+        self.t_flag = self.t_late[W * (W + 1):]                                      # ... and the fixed exchange's flag
+        self.fixed_rows = int(self.FIXED_ROWS)
+        if self.fixed_rows:
+            self.t_blocks_send = torch.zeros((W * self.fixed_rows, 6), dtype=torch.float64, device=dev)
+            self.t_blocks_recv = torch.zeros((W * self.fixed_rows, 6), dtype=torch.float64, device=dev)
+        self.exact_exchanges = 0           # steps whose rows did not fit the fixed blocks
+        self.clock = {}                    # host seconds: enqueuing the steps, waiting at their ends
         self.rows_sent_off_rank = 0        # running totals, for reports
         self.rows_sent_total = 0
         self.steps_done = 0
@@ -279,7 +310,8 @@ class ShardedFilter:
     def _device_step(self, v, omega, dt, alpha, z_meas, r, seed, noise_ints):
         """Generator: enqueues this rank's work and yields the exchanges it needs, in order --
         ("all_reduce_max", t), ("all_gather", out, inp), ("all_gather_read", out, inp) -> numpy,
-        ("all_to_all", send, send_counts, recv_counts) -> recv.  Returns False if a rank had more
+        ("all_to_all", send, send_counts, recv_counts) -> recv, ("all_to_all_fixed", recv, send) with equal blocks,
+        ("read_late", t) -> numpy.  Returns False if a rank had more
         irregular records than the fixed exchange holds (the caller then finishes on the host path)."""
         ctx, rank, world, cap = self.b.ctx, self.rank, self.world, self.RECORD_CAP
         ctx.dshard_sample_max(v, omega, dt, alpha, z_meas, noise_ints, seed, self.mode, self.t_max.data_ptr())
@@ -289,10 +321,25 @@ class ShardedFilter:
         ctx.dshard_scan(self.t_all_chunks.data_ptr(), self.firsts, rank, self.t_rec.data_ptr(), cap)
         yield ("all_gather", self.t_all_rec, self.t_rec)
         ctx.dshard_finalize(self.t_all_rec.data_ptr(), self.firsts, rank, cap, r, self.t_counts.data_ptr())
-        # the one host read of the step: how many rows every rank sends to every other (only rows that some
-        # position draws travel; the all-to-all needs its split sizes on the host)
-        counts = yield ("all_gather_read", self.t_all_counts, self.t_counts)
-        counts = counts.reshape(world, world + 1)
+        if self.fixed_rows:
+            # blocks of a fixed size: the gathered counts stay on the device, which also decides whether every block
+            # was large enough; the host reads that, and the counts for its report, once the step is enqueued
+            yield ("all_gather", self.t_all_counts, self.t_counts)
+            ctx.dshard_pack_fixed(world, rank, self.fixed_rows, self.t_blocks_send.data_ptr())
+            yield ("all_to_all_fixed", self.t_blocks_recv, self.t_blocks_send)
+            ctx.dshard_unpack_fixed(self.t_blocks_recv.data_ptr(), self.t_all_counts.data_ptr(), world, rank,
+                                    self.fixed_rows, r, self.t_flag.data_ptr())
+            late = yield ("read_late", self.t_late)
+            flag = int(late[-1])
+            counts = late[:-1].reshape(world, world + 1)
+            if flag:
+                ctx.dshard_unpack_undo()       # nothing was resampled (the same on every rank)
+        else:
+            # the one host read of the step: how many rows every rank sends to every other (only rows that some
+            # position draws travel; the all-to-all needs its split sizes on the host)
+            counts = yield ("all_gather_read", self.t_all_counts, self.t_counts)
+            counts = counts.reshape(world, world + 1)
+            flag = 2
         if counts[:, -1].any():
             return False
         send_counts = [int(c) for c in counts[rank, :world]]
@@ -301,6 +348,9 @@ class ShardedFilter:
         self.steps_done += 1
         self.rows_sent_total += n_send
         self.rows_sent_off_rank += n_send - send_counts[rank]
+        if flag == 0:
+            return True
+        self.exact_exchanges += 1 if self.fixed_rows else 0
         send = self._torch.empty((max(n_send, 1), 6), dtype=self._torch.float64, device=self.t_max.device)
         if n_send:
             ctx.dshard_pack(world, send.data_ptr())
@@ -310,7 +360,7 @@ class ShardedFilter:
         return True
 
     def _drive(self, gen):
-        return drive_exchanges(gen, self._torch, self.dist, self.stream)
+        return drive_exchanges(gen, self._torch, self.dist, self.stream, self.clock)
 
     def step(self, v, omega, dt, alpha, z_meas, r, seed=0, noise_ints=None, want_idx=False):
         """r = (uniform draw) / M_total, identical on every rank."""

@@ -152,6 +152,13 @@ def _run_lockstep(torch, gens, settle):
         elif op == "all_gather_read":
             cat = torch.cat([q[2] for q in req])
             vals = [cat.cpu().numpy() for _ in req]
+        elif op == "all_to_all_fixed":
+            C = req[0][1].shape[0] // W
+            for d in range(W):
+                for s_ in range(W):
+                    req[d][1][s_ * C:(s_ + 1) * C].copy_(req[s_][2][d * C:(d + 1) * C])
+        elif op == "read_late":
+            vals = [q[1].cpu().numpy() for q in req]
         elif op == "all_to_all":
             offs = [np.concatenate([[0], np.cumsum(q[2])]).astype(int) for q in req]
             for d in range(W):
@@ -170,7 +177,7 @@ def _run_lockstep(torch, gens, settle):
     return done
 
 
-def _lockstep_fn(rank, world, dist, sizes, z_meas, record_cap, flat=False):
+def _lockstep_fn(rank, world, dist, sizes, z_meas, record_cap, flat=False, fixed_rows=None):
     """Several ranks of the device-driven step inside ONE process (one context per rank on the same
     GPU); the exchanges between them are done here with plain tensor operations, so that the
     device kernels that combine the ranks' data see real multi-rank inputs."""
@@ -182,6 +189,8 @@ def _lockstep_fn(rank, world, dist, sizes, z_meas, record_cap, flat=False):
     X, noise, r = _inputs(M)
     W = len(sizes)
     ShardedFilter.RECORD_CAP = record_cap
+    if fixed_rows is not None:
+        ShardedFilter.FIXED_ROWS = fixed_rows
     filt, gens, req = [], [], []
     for k in range(W):
         first = sum(sizes[:k])
@@ -201,7 +210,8 @@ def _lockstep_fn(rank, world, dist, sizes, z_meas, record_cap, flat=False):
     for k, f in enumerate(filt):
         Xo, wo, _ = f.b.ctx.get_particles()
         out.append({"ok": done[k], "idx": f.b.ctx.get_indices() if done[k] else None, "X": Xo, "w": wo,
-                    "rows_sent": f.rows_sent_total, "rows_off_rank": f.rows_sent_off_rank})
+                    "rows_sent": f.rows_sent_total, "rows_off_rank": f.rows_sent_off_rank,
+                    "exact_exchanges": f.exact_exchanges})
     return out
 
 
@@ -225,6 +235,7 @@ def test_device_driven_step_of_several_ranks_equals_one_context(sizes, flat):
     Xr, wr, _ = ref.get_particles()
     res = run_ranks(_lockstep_fn, 1, sizes, z_meas, 256, flat, backend="nccl")[0]
     assert all(x["ok"] for x in res)
+    assert all(x["exact_exchanges"] == 0 for x in res)         # (the default blocks hold what pairs of ranks exchange here)
     assert np.array_equal(np.concatenate([x["idx"] for x in res]), idx)
     sent, off_rank = sum(x["rows_sent"] for x in res), sum(x["rows_off_rank"] for x in res)
     print("%d ranks, %d particles, %s weights: %d rows exchanged (%d between ranks), %d distinct ancestors"
@@ -236,6 +247,37 @@ def test_device_driven_step_of_several_ranks_equals_one_context(sizes, flat):
         assert sent < 0.5 * M
     assert np.array_equal(np.concatenate([x["X"] for x in res]), Xr)
     assert np.array_equal(np.concatenate([x["w"] for x in res]), wr)
+
+
+@pytest.mark.parametrize("fixed_rows,flat", [(0, False), (1, False), (1, True), (3, False)])
+def test_device_driven_step_with_other_block_sizes(fixed_rows, flat):
+    """The row exchange of the device-driven step in blocks of a fixed size per pair of ranks (the default, exercised by
+    the test above), with exact counts read by the host in mid-step (fixed_rows = 0), and with blocks too small for what
+    a pair has to exchange: the device says so, nothing is resampled, and the step is finished with exact counts --
+    the same particles either way."""
+    from slam_amd import _lib
+    sizes = (8192, 8192, 11000)
+    M = sum(sizes)
+    X, noise, r = _inputs(M)
+    ref = _setup(_lib.F32, flat)
+    z_meas = ref.raycast(np.array([3.0, 4.5, 0.0]), want_hits=False)[0][0]
+    ref.set_particles(X)
+    ref.shard_sample(1.5, 0.0, 0.1, ALPHA, z_meas, noise, 99, _lib.W_LOG)
+    ref.normalise(_lib.W_LOG)
+    idx = ref.resample(r, _lib.RESAMPLE_PARALLEL)
+    Xr, wr, _ = ref.get_particles()
+    res = run_ranks(_lockstep_fn, 1, sizes, z_meas, 256, flat, fixed_rows, backend="nccl")[0]
+    assert all(x["ok"] for x in res)
+    assert np.array_equal(np.concatenate([x["idx"] for x in res]), idx)
+    assert np.array_equal(np.concatenate([x["X"] for x in res]), Xr)
+    assert np.array_equal(np.concatenate([x["w"] for x in res]), wr)
+    off_rank = sum(x["rows_off_rank"] for x in res)
+    exact = [x["exact_exchanges"] for x in res]
+    print("blocks of %d rows, %s weights: %d rows between ranks, steps finished with exact counts %s"
+          % (fixed_rows, "equal" if flat else "peaked", off_rank, exact))
+    assert len(set(exact)) == 1                                # the flag is the same on every rank
+    if fixed_rows == 0:
+        assert exact[0] == 0
 
 
 def test_device_driven_step_reports_record_overflow():
