@@ -464,9 +464,11 @@ def main():
             "roofline": roofline(a, M, B, ray_ms, n_ray, copy_gbs, kernel_name),
             "exchange": ({"rows_per_step_max_over_ranks": ex_rows,
                           "bytes_between_ranks_per_step_max_over_ranks": 48.0 * ex_off,
-                          "host_reads_per_step": (("1, after the step's last kernel has been enqueued (row blocks of %d per pair of ranks)"
-                                                   % filt.fixed_rows) if getattr(filt, "fixed_rows", 0) else 1)
-                          if filt.device_path else "host-combined: about 13",
+                          "host_reads_per_step": 1 if filt.device_path else "host-combined: about 13",
+                          "host_read_is": (("after the step's last kernel has been enqueued (rows travel in blocks of %d per pair "
+                                            "of ranks; the device says whether they were large enough)" % filt.fixed_rows)
+                                           if getattr(filt, "fixed_rows", 0) else "in mid-step: the row counts of the all-to-all")
+                          if filt.device_path else None,
                           "steps_finished_with_exact_counts": getattr(filt, "exact_exchanges", None),
                           "host_ms_per_step": ({k: 1e3 * v / max(getattr(filt, "steps_done", 0), 1)
                                                 for k, v in getattr(filt, "clock", {}).items()} or None),
