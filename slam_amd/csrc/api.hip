@@ -1219,9 +1219,8 @@ int mclhip_dshard_sample_max(mclhip_ctx* c, double v, double omega, double dt, c
   }
   MCL_TRY(enqueue_sample(c, v, omega, dt, alpha, noise_ints ? 1 : 2, seed, c->spans, weight_mode == MCLHIP_W_PRODUCT));
   span_begin(c, c->spans, 2);
-  MCL_TRY(launch_shard_max_logw(c));
+  MCL_TRY(launch_shard_max_logw(c, d_max_out));   // (written where the caller reduces it: no copy in between)
   span_end(c, c->spans);
-  MCL_HIP(c, hipMemcpyAsync(d_max_out, c->scal + 1, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   return MCLHIP_OK;
 }
 
@@ -1229,12 +1228,9 @@ int mclhip_dshard_weights(mclhip_ctx* c, const double* d_gmax, double* d_chunks_
   MCL_TRY(use(c));
   MCL_TRY(need(c, false, false, true));
   if (!d_gmax || !d_chunks_out) return fail(c, MCLHIP_E_ARG, "device pointer is NULL");
-  const int64_t nch = (c->M + kSumChunk - 1) / kSumChunk;
-  MCL_HIP(c, hipMemcpyAsync(c->scal + 1, d_gmax, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   span_begin(c, c->spans, 2);
-  MCL_TRY(launch_dshard_weights(c));
+  MCL_TRY(launch_dshard_weights(c, d_gmax, d_chunks_out));   // (reads the maximum, leaves the chunk sums, where the caller keeps them)
   span_end(c, c->spans);
-  MCL_HIP(c, hipMemcpyAsync(d_chunks_out, c->chunk_sums, nch * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   return MCLHIP_OK;
 }
 

@@ -260,6 +260,7 @@ struct mclhip_ctx {
   void* g_bases = nullptr;
   void* rows_send = nullptr; int64_t rows_send_cap = 0;   // packed rows handed to / received from the exchange
   void* rows_recv = nullptr; int64_t rows_recv_cap = 0;
+  bool dshard_tiles_ready = false;   // c->cdf_approx holds the tile sums of launch_dshard_weights
   void* rows_self = nullptr; int64_t rows_self_cap = 0;   // the fixed-block exchange: the rows a rank draws from itself
   int64_t* sel = nullptr; int64_t sel_cap = 0;            // local row behind every place of the send buffer (drawn-row exchange)
   int64_t drawn_total = 0;                                // rows the last plan sends in all
@@ -351,9 +352,9 @@ int launch_compute_px(mclhip_ctx* c, const double* z, const double* zt, int64_t 
 int launch_normalise(mclhip_ctx* c, int mode);
 int launch_resample(mclhip_ctx* c, double r, int algo);
 int launch_normalise_resample(mclhip_ctx* c, int mode, double r);   // the two above in six launches (fused update)
-int launch_shard_max_logw(mclhip_ctx* c);
+int launch_shard_max_logw(mclhip_ctx* c, double* d_also = nullptr);   // (d_also: a second place for the maximum, on the device)
 int launch_shard_weights(mclhip_ctx* c, int mode, double gmax);
-int launch_dshard_weights(mclhip_ctx* c);
+int launch_dshard_weights(mclhip_ctx* c, const double* d_gmax, double* d_chunks_out);
 int launch_shard_scan(mclhip_ctx* c, double total, double approx_offset, int64_t first_index, const double* d_offset = nullptr);
 struct ShardLayout {   // who holds what of the global particle vector (at most 64 ranks)
   int world, rank, cmax;
@@ -368,7 +369,8 @@ int launch_fs_dshard_finalize_raw(mclhip_ctx* c, const void* d_all_rec, const Sh
 int launch_shard_finalize(mclhip_ctx* c, const void* d_records, int64_t nrec, void* d_bases, uint64_t P_off,
                           uint32_t F_off, const unsigned long long* d_meta = nullptr);
 int launch_count_below(mclhip_ctx* c, const double* d_U, int nu, int64_t* d_counts);
-int launch_plan_drawn(mclhip_ctx* c, const ShardLayout& lay, double r, int64_t* d_counts, const unsigned long long* meta);
+int launch_plan_drawn(mclhip_ctx* c, const ShardLayout& lay, double r, int64_t* d_counts, const unsigned long long* meta,
+                      bool ends_done = false);   // (ends_done: the draw ends are in c->kscan already)
 int launch_pack_drawn(mclhip_ctx* c, int world, double* d_dst, int64_t* d_sel);
 int launch_unpack_drawn(mclhip_ctx* c, const double* d_rows, int64_t L, double r, bool keep_pos);
 int launch_pack_fixed(mclhip_ctx* c, int world, int rank, int64_t cap, double* d_dst, double* d_self);

@@ -133,14 +133,18 @@ __global__ __launch_bounds__(256) void max_partial_kernel(const double* __restri
 }
 
 __global__ __launch_bounds__(256) void max_final_kernel(const double* __restrict__ part, int np,
-                                                        double* __restrict__ scal) {
+                                                        double* __restrict__ scal, double* __restrict__ also = nullptr) {
   __shared__ double sm[4];
   double m = -INFINITY;
   for (int i = threadIdx.x; i < np; i += blockDim.x) m = fmax(m, part[i]);
   for (int d = 32; d >= 1; d >>= 1) m = fmax(m, __shfl_xor(m, d, 64));
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) scal[1] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+  if (threadIdx.x == 0) {
+    const double t = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+    scal[1] = t;
+    if (also) also[0] = t;       // (the caller's own place for it)
+  }
 }
 
 
@@ -339,12 +343,7 @@ struct StoreKF {
 };
 
 // One wavefront walks the irregular elements in order.
-__global__ __launch_bounds__(64) void replay_kernel(const IrrRecord* __restrict__ irr,
-                                                    const unsigned int* __restrict__ fs, int64_t n,
-                                                    int64_t nirr_given, RunBase* __restrict__ bases,
-                                                    const unsigned long long* __restrict__ nirr_ptr) {
-  const int lane = threadIdx.x;
-  const unsigned int nirr = nirr_ptr ? (unsigned int)nirr_ptr[0] : (fs ? fs[n - 1] : (unsigned int)nirr_given);
+__device__ inline void replay_body(const IrrRecord* __restrict__ irr, unsigned int nirr, RunBase* __restrict__ bases, int lane) {
   double c = 0.0;
   unsigned long long Pprev = 0ull;
   int e_run = -1000;
@@ -365,6 +364,14 @@ __global__ __launch_bounds__(64) void replay_kernel(const IrrRecord* __restrict_
     }
     if ((unsigned)lane < cnt) bases[base + lane] = mine;
   }
+}
+
+__global__ __launch_bounds__(64) void replay_kernel(const IrrRecord* __restrict__ irr,
+                                                    const unsigned int* __restrict__ fs, int64_t n,
+                                                    int64_t nirr_given, RunBase* __restrict__ bases,
+                                                    const unsigned long long* __restrict__ nirr_ptr) {
+  const unsigned int nirr = nirr_ptr ? (unsigned int)nirr_ptr[0] : (fs ? fs[n - 1] : (unsigned int)nirr_given);
+  replay_body(irr, nirr, bases, threadIdx.x);
 }
 
 __global__ void finalize_cdf_kernel(const unsigned long long* __restrict__ ks, const unsigned int* __restrict__ fs,
@@ -611,9 +618,11 @@ struct TileScan {
   KF tile_total;
 };
 
+// (shard_off, i0: what stands before local element 0 on a rank that holds a later part of the vector -- its approximate
+// share of the total, and its global index)
 template <bool DIVIDE>
 __device__ inline void scan_tile(TileScan& T, double* __restrict__ w, int64_t n, const double* __restrict__ tile_sums,
-                                 double total) {
+                                 double total, double shard_off = 0.0, int64_t i0 = 0) {
   __shared__ double s_red[4];
   __shared__ double s_off;
   // un-normalised weight before this tile: every thread adds a strided share of the earlier tiles' sums
@@ -622,7 +631,7 @@ __device__ inline void scan_tile(TileScan& T, double* __restrict__ w, int64_t n,
   for (int d = 32; d >= 1; d >>= 1) part = part + __shfl_xor(part, d, 64);
   if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = part;
   __syncthreads();
-  if (threadIdx.x == 0) s_off = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) / total;
+  if (threadIdx.x == 0) s_off = shard_off + ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) / total;
   __syncthreads();
   const double off = s_off;
   const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
@@ -645,7 +654,7 @@ __device__ inline void scan_tile(TileScan& T, double* __restrict__ w, int64_t n,
   for (int j = 0; j < kScanItems; ++j) {
     const double prev = run;
     run = run + T.wn[j];
-    T.kf[j] = (base + j < n) ? classify_element(base + j, T.wn[j], prev, run) : KF{0ull, 0u};
+    T.kf[j] = (base + j < n) ? classify_element(i0 + base + j, T.wn[j], prev, run) : KF{0ull, 0u};
     ksum = ksum + T.kf[j];
   }
   T.local = block_incl_scan<KF>(ksum, &T.tile_total);
@@ -686,17 +695,58 @@ __global__ __launch_bounds__(kScanBlock) void normalise_classify_kernel(double* 
   if (threadIdx.x == 0) tile_kf[blockIdx.x] = T.tile_total;
 }
 
+// the same for one rank's part of the vector: the total is the sum of EVERY rank's chunk sums, added left to right in
+// rank order (== np.sum of the whole vector); what the ranks before this one hold, over the total, is where this
+// rank's approximate running sum starts (-> scal[5], for records_kernel<true>)
+__global__ __launch_bounds__(kScanBlock) void normalise_classify_shard_kernel(double* __restrict__ w, int64_t n,
+                                                                              const double* __restrict__ all_chunks, ShardLayout lay,
+                                                                              const double* __restrict__ tile_sums,
+                                                                              KF* __restrict__ tile_kf, double* __restrict__ scal,
+                                                                              unsigned int* __restrict__ done_counter) {
+  __shared__ double s_chunk[kMaxFusedChunks];
+  __shared__ double s_tb[2];
+  int at = 0;
+  for (int r = 0; r < lay.world; ++r) {
+    const double* src = all_chunks + (size_t)r * lay.cmax;
+    for (int j = threadIdx.x; j < lay.nchunks[r]; j += blockDim.x) s_chunk[at + j] = src[j];
+    at += lay.nchunks[r];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0, below = 0.0;
+    int i = 0;
+    for (int r = 0; r < lay.world; ++r) {
+      if (r == lay.rank) below = t;
+      for (int j = 0; j < lay.nchunks[r]; ++j) t = t + s_chunk[i++];
+    }
+    s_tb[0] = t;
+    s_tb[1] = below / t;
+  }
+  __syncthreads();
+  const double total = s_tb[0], shard_off = s_tb[1];
+  if (blockIdx.x == 0 && threadIdx.x == 0) { scal[0] = total; scal[5] = shard_off; *done_counter = 0u; }
+  TileScan T;
+  scan_tile<true>(T, w, n, tile_sums, total, shard_off, lay.first[lay.rank]);
+  if (threadIdx.x == 0) tile_kf[blockIdx.x] = T.tile_total;
+}
+
+// SHARD: one rank's part of the vector (global index of its first element i0, its approximate offset in scal[5]); the
+// block that finishes last does not replay the records -- the list is not whole before every rank's part of it has
+// been gathered -- but exports them: the integer total, their number, and the first `cap` of them -> out
+template <bool SHARD>
 __global__ __launch_bounds__(kScanBlock) void records_kernel(double* __restrict__ wn, int64_t n,
                                                              const double* __restrict__ tile_sums,
                                                              const KF* __restrict__ tile_kf, const double* __restrict__ scal,
                                                              unsigned long long* __restrict__ ks, unsigned int* __restrict__ fs,
                                                              IrrRecord* __restrict__ irr, RunBase* __restrict__ bases,
-                                                             unsigned int* __restrict__ done_counter) {
+                                                             unsigned int* __restrict__ done_counter, int64_t i0,
+                                                             int cap, unsigned long long* __restrict__ out) {
   __shared__ KF s_kred[4];
   __shared__ int s_last;
   const double total = scal[0];
   TileScan T;
-  scan_tile<false>(T, wn, n, tile_sums, total);
+  scan_tile<false>(T, wn, n, tile_sums, total, SHARD ? scal[5] : 0.0, SHARD ? i0 : 0);
+  unsigned long long* const ktot_slot = reinterpret_cast<unsigned long long*>(const_cast<double*>(scal) + 7);   // SHARD: the integer total
   // integer prefix and record count of the earlier tiles (exact, any order)
   KF part = KF{0ull, 0u};
   for (int j = threadIdx.x; j < (int)blockIdx.x; j += kScanBlock) part = part + tile_kf[j];
@@ -719,11 +769,14 @@ __global__ __launch_bounds__(kScanBlock) void records_kernel(double* __restrict_
         // the records (and their number, below) are read by another block of this launch: agent-scope stores,
         // which go through to memory, and agent-scope loads on the reading side
         IrrRecord* dst = irr + (run.f - 1);
-        __hip_atomic_store(&dst->i, base + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&dst->i, (SHARD ? i0 : 0) + base + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(reinterpret_cast<long long*>(&dst->w), __double_as_longlong(T.wn[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&dst->P, run.k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      if (base + j == n - 1) __hip_atomic_store(done_counter + 1, run.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // number of records
+      if (base + j == n - 1) {
+        __hip_atomic_store(done_counter + 1, run.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // number of records
+        if constexpr (SHARD) __hip_atomic_store(ktot_slot, run.k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
   // The block that finishes last walks the irregular records (the serial step of the method).  Hand-over between
@@ -754,6 +807,25 @@ __global__ __launch_bounds__(kScanBlock) void records_kernel(double* __restrict_
     s_last = before == gridDim.x - 1;
   }
   __syncthreads();
+  if constexpr (SHARD) {
+    if (!s_last) return;
+    const unsigned int nrec = __hip_atomic_load(done_counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+      out[0] = __hip_atomic_load(ktot_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      out[1] = nrec;
+    }
+    IrrRecord* dst = reinterpret_cast<IrrRecord*>(out + 2);
+    const unsigned int m = nrec < (unsigned int)cap ? nrec : (unsigned int)cap;
+    for (unsigned int j = threadIdx.x; j < m; j += blockDim.x) {
+      const IrrRecord* src = irr + j;
+      IrrRecord rec;
+      rec.i = __hip_atomic_load(&src->i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      rec.w = __longlong_as_double(__hip_atomic_load(reinterpret_cast<const long long*>(&src->w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      rec.P = __hip_atomic_load(&src->P, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      dst[j] = rec;
+    }
+    return;
+  }
   if (!s_last || threadIdx.x >= 64) return;
   // replay (see replay_kernel), by the first wavefront of the last block
   const int lane = threadIdx.x;
@@ -806,9 +878,9 @@ static int normalise_resample_typed(mclhip_ctx* c, int mode, double r) {
   }
   hipLaunchKernelGGL(normalise_classify_kernel, dim3(ntile), dim3(kScanBlock), 0, c->stream, w, n,
                      (const double*)c->chunk_sums, nchunks, (const double*)tile_sums, (KF*)c->blk_b, c->scal, done_counter);
-  hipLaunchKernelGGL(records_kernel, dim3(ntile), dim3(kScanBlock), 0, c->stream, w, n, (const double*)tile_sums,
+  hipLaunchKernelGGL(records_kernel<false>, dim3(ntile), dim3(kScanBlock), 0, c->stream, w, n, (const double*)tile_sums,
                      (const KF*)c->blk_b, (const double*)c->scal, (unsigned long long*)c->kscan, c->fscan,
-                     (IrrRecord*)c->irr, (RunBase*)c->bases, done_counter);
+                     (IrrRecord*)c->irr, (RunBase*)c->bases, done_counter, (int64_t)0, 0, (unsigned long long*)nullptr);
   hipLaunchKernelGGL(finalize_cdf_kernel, dim3(g), dim3(256), 0, c->stream, (const unsigned long long*)c->kscan,
                      c->fscan, (const RunBase*)c->bases, n, 0ull, 0u, c->cdf_exact, (const unsigned long long*)nullptr);
   hipLaunchKernelGGL(search_gather_kernel<T>, dim3(g), dim3(256), 0, c->stream, c->cdf_exact, n, r, (const T*)c->px[a],
@@ -847,10 +919,10 @@ __global__ void exp_shift_by_kernel(const double* __restrict__ logw, double* __r
   w[i] = (mx == -INFINITY) ? 0.0 : exp(logw[i] - mx);
 }
 
-int launch_shard_max_logw(mclhip_ctx* c) {
+int launch_shard_max_logw(mclhip_ctx* c, double* d_also) {
   const int np = 1024;
   hipLaunchKernelGGL(max_partial_kernel, dim3(np), dim3(256), 0, c->stream, c->logw, c->M, (double*)c->blk_a);
-  hipLaunchKernelGGL(max_final_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)c->blk_a, np, c->scal);
+  hipLaunchKernelGGL(max_final_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)c->blk_a, np, c->scal, d_also);
   MCL_HIP(c, hipGetLastError());
   return MCLHIP_OK;
 }
@@ -870,12 +942,15 @@ int launch_shard_weights(mclhip_ctx* c, int mode, double gmax) {
 }
 
 // log-mode weights with the global maximum already in scal[1] (device-driven path)
-int launch_dshard_weights(mclhip_ctx* c) {
+// (the chunk sums go straight to where the caller gathers them from; the sums per 2048-tile, for the approximate scan
+// of launch_dshard_scan, to c->cdf_approx; scal[1] = the global maximum)
+int launch_dshard_weights(mclhip_ctx* c, const double* d_gmax, double* d_chunks_out) {
   const int64_t n = c->M;
   double* w = c->w[c->cur];
   const int nchunks = (int)((n + kSumChunk - 1) / kSumChunk);
-  hipLaunchKernelGGL(chunk_sum_kernel<true>, dim3(nchunks), dim3(512), 0, c->stream, w, n, c->chunk_sums,
-                     (const double*)c->logw, (const double*)c->scal);
+  hipLaunchKernelGGL(chunk_tile_sum_kernel<true>, dim3(nchunks), dim3(512), 0, c->stream, w, n, d_chunks_out, c->cdf_approx,
+                     (const double*)c->logw, d_gmax, 1, c->scal);
+  c->dshard_tiles_ready = true;
   MCL_HIP(c, hipGetLastError());
   return MCLHIP_OK;
 }
@@ -957,8 +1032,8 @@ __global__ void export_records_kernel(const unsigned long long* __restrict__ ks,
 // every rank's exported block -> one global record list with global integer prefixes;
 // meta[0] = records in the list, meta[1] / meta[2] = this rank's integer / record offset,
 // meta[3] = 1 when some rank had more records than fit (the caller then takes the host path)
-__global__ void merge_records_kernel(const unsigned long long* __restrict__ all, int world, int rank, int cap,
-                                     IrrRecord* __restrict__ g_records, unsigned long long* __restrict__ meta) {
+__device__ inline void merge_records_body(const unsigned long long* __restrict__ all, int world, int rank, int cap,
+                                          IrrRecord* __restrict__ g_records, unsigned long long* __restrict__ meta) {
   __shared__ unsigned long long p_off[65];
   __shared__ unsigned long long f_off[65];
   const size_t stride = 2 + (size_t)cap * (sizeof(IrrRecord) / sizeof(unsigned long long));
@@ -984,6 +1059,11 @@ __global__ void merge_records_kernel(const unsigned long long* __restrict__ all,
       g_records[f_off[s] + j] = rec;
     }
   }
+}
+
+__global__ void merge_records_kernel(const unsigned long long* __restrict__ all, int world, int rank, int cap,
+                                     IrrRecord* __restrict__ g_records, unsigned long long* __restrict__ meta) {
+  merge_records_body(all, world, rank, cap, g_records, meta);
 }
 
 // ---- which rows travel: only those that some position draws --------------------------------------------------
@@ -1171,40 +1251,45 @@ __global__ __launch_bounds__(256) void pack_fixed_kernel(const T* __restrict__ x
   }
 }
 
-// meta[0] = 0 fine, 1 a rank's record merge overflowed (nothing was planned), 2 some pair's rows exceed `cap`;
-// meta[1] = rows this rank receives; meta[2 + s] = how many of them come before source s's.  The flag is the same on
-// every rank: it is formed from the whole gathered matrix.
-__global__ void exchange_meta_kernel(const int64_t* __restrict__ all_counts, int world, int rank, int64_t cap,
-                                     int64_t* __restrict__ meta, int64_t* __restrict__ flag_out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  int64_t flag = 0;
-  for (int s = 0; s < world; ++s) {
-    if (all_counts[(size_t)s * (world + 1) + world] != 0) flag = 1;
-    for (int d = 0; d < world && flag != 1; ++d)
-      if (s != d && all_counts[(size_t)s * (world + 1) + d] > cap) flag = 2;
-  }
-  int64_t off = 0;
-  for (int s = 0; s < world; ++s) {
-    meta[2 + s] = off;
-    off += all_counts[(size_t)s * (world + 1) + rank];
-  }
-  meta[2 + world] = off;
-  meta[1] = off;
-  meta[0] = flag;
-  flag_out[0] = flag;
-}
-
 // unpack_drawn_kernel over rows that stand in one block per source (the rank's own in its own buffer)
+// Every block reads the gathered counts for itself (all_counts[s][d]: rows rank s has for rank d; all_counts[s][world]:
+// rank s planned nothing because a record merge overflowed): how many rows come from every source, and the flag --
+// 0 fine, 1 a record merge overflowed, 2 some pair's rows exceed `cap` -- which is the same on every rank (it is formed
+// from the whole matrix) and goes to flag_out.
 template <typename T>
 __global__ __launch_bounds__(256) void unpack_fixed_kernel(const double* __restrict__ recv, const double* __restrict__ self_rows,
-                                                           const int64_t* __restrict__ meta, int world, int rank, int64_t cap,
+                                                           const int64_t* __restrict__ all_counts, int world, int rank, int64_t cap,
+                                                           int64_t* __restrict__ flag_out,
                                                            int64_t first_index, int64_t m_total, int64_t n, double r,
                                                            T* __restrict__ x2, T* __restrict__ y2, T* __restrict__ th2,
                                                            double* __restrict__ w2, int64_t* __restrict__ idx) {
   __shared__ int64_t s_off[66];
-  for (int k = threadIdx.x; k < world + 1; k += blockDim.x) s_off[k] = meta[2 + k];
-  const int64_t flag = meta[0];
+  __shared__ int s_flag[256];
+  {
+    int f = 0;
+    for (int k = threadIdx.x; k < world * (world + 1); k += blockDim.x) {
+      const int s_ = k / (world + 1), d = k - s_ * (world + 1);
+      const int64_t v = all_counts[k];
+      if (d == world) { if (v != 0) f = 1; }
+      else if (s_ != d && v > cap && f == 0) f = 2;
+    }
+    s_flag[threadIdx.x] = f;
+  }
   __syncthreads();
+  if (threadIdx.x == 0) {
+    int f = 0;
+    for (int k = 0; k < 256; ++k) f = (s_flag[k] == 1 || f == 1) ? 1 : (s_flag[k] == 2 ? 2 : f);
+    int64_t off = 0;
+    for (int s_ = 0; s_ < world; ++s_) {
+      s_off[s_] = off;
+      off += all_counts[(size_t)s_ * (world + 1) + rank];
+    }
+    s_off[world] = off;
+    s_flag[0] = f;
+    if (blockIdx.x == 0) flag_out[0] = f;
+  }
+  __syncthreads();
+  const int flag = s_flag[0];
   if (flag != 0) return;
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
@@ -1265,15 +1350,13 @@ int launch_unpack_fixed(mclhip_ctx* c, const double* d_recv, const double* d_sel
   const int64_t n = c->M;
   const int b = 1 - c->cur;
   const unsigned g = (unsigned)((n + 255) / 256);
-  int64_t* meta = c->small_i + 8 + 4 * 64 + 128;               // behind the merge's words, the slices and the host path's counts
-  hipLaunchKernelGGL(exchange_meta_kernel, dim3(1), dim3(64), 0, c->stream, d_all_counts, world, rank, cap, meta, d_flag_out);
   if (c->dtype == MCLHIP_F32)
-    hipLaunchKernelGGL(unpack_fixed_kernel<float>, dim3(g), dim3(256), 0, c->stream, d_recv, d_self, (const int64_t*)meta, world,
-                       rank, cap, c->first_index, c->m_total, n, r, (float*)c->px[b], (float*)c->py[b], (float*)c->pth[b],
+    hipLaunchKernelGGL(unpack_fixed_kernel<float>, dim3(g), dim3(256), 0, c->stream, d_recv, d_self, d_all_counts, world,
+                       rank, cap, d_flag_out, c->first_index, c->m_total, n, r, (float*)c->px[b], (float*)c->py[b], (float*)c->pth[b],
                        c->w[b], c->idx);
   else
-    hipLaunchKernelGGL(unpack_fixed_kernel<double>, dim3(g), dim3(256), 0, c->stream, d_recv, d_self, (const int64_t*)meta, world,
-                       rank, cap, c->first_index, c->m_total, n, r, (double*)c->px[b], (double*)c->py[b], (double*)c->pth[b],
+    hipLaunchKernelGGL(unpack_fixed_kernel<double>, dim3(g), dim3(256), 0, c->stream, d_recv, d_self, d_all_counts, world,
+                       rank, cap, d_flag_out, c->first_index, c->m_total, n, r, (double*)c->px[b], (double*)c->py[b], (double*)c->pth[b],
                        c->w[b], c->idx);
   MCL_HIP(c, hipGetLastError());
   c->cur = b;
@@ -1281,6 +1364,26 @@ int launch_unpack_fixed(mclhip_ctx* c, const double* d_recv, const double* d_sel
 }
 
 int launch_dshard_scan(mclhip_ctx* c, const double* d_all_chunks, const ShardLayout& lay, void* d_rec_out, int cap) {
+  int all_chunks = 0;
+  for (int r = 0; r < lay.world; ++r) all_chunks += lay.nchunks[r];
+  const bool tiles = c->dshard_tiles_ready;   // (the tile sums of launch_dshard_weights; spent below either way)
+  c->dshard_tiles_ready = false;
+  if (all_chunks <= kMaxFusedChunks && tiles) {
+    // two launches (see normalise_resample_typed): total and offset by every block for itself, division, approximate
+    // scan and classification; then integer prefixes and records, exported by the block that finishes last
+    const int64_t n = c->M;
+    double* w = c->w[c->cur];
+    const int ntile = (int)((n + kScanTile - 1) / kScanTile);
+    unsigned int* done_counter = reinterpret_cast<unsigned int*>(c->scal + 6);
+    hipLaunchKernelGGL(normalise_classify_shard_kernel, dim3(ntile), dim3(kScanBlock), 0, c->stream, w, n, d_all_chunks, lay,
+                       (const double*)c->cdf_approx, (KF*)c->blk_b, c->scal, done_counter);
+    hipLaunchKernelGGL(records_kernel<true>, dim3(ntile), dim3(kScanBlock), 0, c->stream, w, n, (const double*)c->cdf_approx,
+                       (const KF*)c->blk_b, (const double*)c->scal, (unsigned long long*)c->kscan, c->fscan,
+                       (IrrRecord*)c->irr, (RunBase*)c->bases, done_counter, c->first_index, cap,
+                       (unsigned long long*)d_rec_out);
+    MCL_HIP(c, hipGetLastError());
+    return MCLHIP_OK;
+  }
   hipLaunchKernelGGL(shard_totals_kernel, dim3(1), dim3(64), 0, c->stream, d_all_chunks, lay, c->scal);
   MCL_TRY_W(launch_shard_scan(c, 0.0, 0.0, c->first_index, c->scal + 5));
   hipLaunchKernelGGL(export_records_kernel, dim3(1), dim3(256), 0, c->stream, (const unsigned long long*)c->kscan,
@@ -1289,7 +1392,7 @@ int launch_dshard_scan(mclhip_ctx* c, const double* d_all_chunks, const ShardLay
   return MCLHIP_OK;
 }
 
-int launch_plan_drawn(mclhip_ctx* c, const ShardLayout& lay, double r, int64_t* d_counts, const unsigned long long* meta);
+
 
 // ---- FastSLAM over several GPUs, device-driven: the weight vector is normalised by the Python-order sum of
 // fast_slam1.py:411-418 (the last running sum of the raw weights, floored at 1e-8), not by np.sum.  Two rounds of the
@@ -1334,26 +1437,57 @@ int launch_fs_dshard_finalize_raw(mclhip_ctx* c, const void* d_all_rec, const Sh
   return MCLHIP_OK;
 }
 
+// merge_records_kernel and replay_kernel in one launch: the block merges, its first wavefront replays
+__global__ __launch_bounds__(256) void merge_replay_kernel(const unsigned long long* __restrict__ all, int world, int rank, int cap,
+                                                           IrrRecord* __restrict__ g_records, unsigned long long* __restrict__ meta,
+                                                           RunBase* __restrict__ bases) {
+  merge_records_body(all, world, rank, cap, g_records, meta);
+  __syncthreads();                       // (one block: its stores are visible to its own threads behind the barrier)
+  if (threadIdx.x < 64) replay_body(g_records, (unsigned int)meta[0], bases, threadIdx.x);
+}
+
+// finalize_cdf_kernel and draw_ends_kernel in one launch
+__global__ void finalize_draw_kernel(const unsigned long long* ks, const unsigned int* __restrict__ fs,
+                                     const RunBase* __restrict__ bases, int64_t n, double* __restrict__ cdf,
+                                     const unsigned long long* __restrict__ off_ptr, int64_t m_total, double r, int last_rank,
+                                     int64_t* G) {   // (G is ks's own memory: every thread reads its element before it writes it)
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long P_off = off_ptr[1];
+  const unsigned int F_off = (unsigned int)off_ptr[2];
+  const RunBase b = bases[F_off + fs[i] - 1];
+  const unsigned long long k = ks[i];
+  const double ci = b.c + (double)(P_off + k - b.P) * ldexp(1.0, b.e - 52);  // exact (see finalize_cdf_kernel)
+  cdf[i] = ci;
+  G[i] = (last_rank && i == n - 1) ? m_total : first_above(ci, m_total, r);   // (overwrites ks[i]: read above)
+}
+
 int launch_dshard_finalize(mclhip_ctx* c, const void* d_all_rec, const ShardLayout& lay, int cap, double r,
                            int64_t* d_counts) {
   unsigned long long* meta = reinterpret_cast<unsigned long long*>(c->small_i);   // [4] of the 1024-entry staging
-  hipLaunchKernelGGL(merge_records_kernel, dim3(1), dim3(256), 0, c->stream, (const unsigned long long*)d_all_rec,
-                     lay.world, lay.rank, cap, (IrrRecord*)c->g_records, meta);
-  MCL_TRY_W(launch_shard_finalize(c, c->g_records, 0, c->g_bases, 0, 0, meta));
-  return launch_plan_drawn(c, lay, r, d_counts, meta);
+  const int64_t n = c->M;
+  const unsigned g = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(merge_replay_kernel, dim3(1), dim3(256), 0, c->stream, (const unsigned long long*)d_all_rec,
+                     lay.world, lay.rank, cap, (IrrRecord*)c->g_records, meta, (RunBase*)c->g_bases);
+  hipLaunchKernelGGL(finalize_draw_kernel, dim3(g), dim3(256), 0, c->stream, (const unsigned long long*)c->kscan, c->fscan,
+                     (const RunBase*)c->g_bases, n, c->cdf_exact, (const unsigned long long*)meta, c->m_total, r,
+                     lay.rank == lay.world - 1 ? 1 : 0, reinterpret_cast<int64_t*>(c->kscan));
+  return launch_plan_drawn(c, lay, r, d_counts, meta, true);
 }
 
 // which local rows are drawn at all, and by the positions of which rank: only those travel.  Needs the exact running
 // sums in c->cdf_exact; leaves the draw ends in c->kscan, the scan of the drawn flags in c->fscan, the slices behind
 // c->small_i + 8 and the row counts per destination (+ the overflow word) in d_counts.
-int launch_plan_drawn(mclhip_ctx* c, const ShardLayout& lay, double r, int64_t* d_counts, const unsigned long long* meta) {
+int launch_plan_drawn(mclhip_ctx* c, const ShardLayout& lay, double r, int64_t* d_counts, const unsigned long long* meta,
+                      bool ends_done) {
   const int64_t n = c->M;
   const unsigned g = (unsigned)((n + 255) / 256);
   const int ntile = (int)((n + kScanTile - 1) / kScanTile);
   int64_t* G = reinterpret_cast<int64_t*>(c->kscan);           // the integer prefixes are spent once the running sums exist
   unsigned int* S = c->fscan;                                  // likewise the record counts
-  hipLaunchKernelGGL(draw_ends_kernel, dim3(g), dim3(256), 0, c->stream, (const double*)c->cdf_exact, n, c->m_total, r,
-                     lay.rank == lay.world - 1 ? 1 : 0, G);
+  if (!ends_done)
+    hipLaunchKernelGGL(draw_ends_kernel, dim3(g), dim3(256), 0, c->stream, (const double*)c->cdf_exact, n, c->m_total, r,
+                       lay.rank == lay.world - 1 ? 1 : 0, G);
   DrawnFlagLoader fl{G};
   StoreU32 su{S};
   hipLaunchKernelGGL((scan_reduce_kernel<unsigned int, DrawnFlagLoader>), dim3(ntile), dim3(kScanBlock), 0, c->stream, fl, n,
