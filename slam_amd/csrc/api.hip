@@ -304,7 +304,6 @@ static int need(mclhip_ctx* c, bool map, bool sensor, bool particles) {
 static int enqueue_sample(mclhip_ctx* c, double v, double omega, double dt, const double* alpha, int noise_mode,
                           uint64_t seed, std::vector<mclhip_ctx::Span>& spans, bool want_product,
                           const double* d_range_noise = nullptr, double rn_sigma = 0.0, uint32_t ints_span = 2001) {
-  MCL_TRY(launch_beam_table(c));
   MotionParams mp = make_motion_params(c, v, omega, dt, alpha, noise_mode, seed);
   mp.ints_span = ints_span;
   const int a = c->cur;
@@ -314,6 +313,9 @@ static int enqueue_sample(mclhip_ctx* c, double v, double omega, double dt, cons
   span_begin(c, spans, 1);
   MCL_TRY(launch_motion(c, c->px[a], c->py[a], c->pth[a], c->pm, c->M, mp, c->noise, c->dtype));
   span_end(c, spans);
+  // (the measurement's table is the query's business: behind the motion kernel, so that a caller that has just waited
+  // for the GPU gets it started one launch sooner)
+  MCL_TRY(launch_beam_table(c));
   // (timed inside: group 0 around its kernel, or around the first of its two kernels and group 5 around the second)
   // the raw product is only formed when somebody will read it: it costs one dependent multiply per beam
   MCL_TRY(launch_raycast(c, c->px[a], c->py[a], c->pth[a], c->pm, c->M, c->dtype, want_product ? c->w[a] : nullptr,

@@ -210,7 +210,13 @@ def drive_exchanges(gen, torch, dist, stream, clock=None):
                         dist.all_to_all_single(recv, send)
                 elif op == "read_late":
                     t_wait = time.perf_counter()
-                    val = req[1].cpu().numpy()             # everything of the step is enqueued: the one wait, at its end
+                    # everything of the step is enqueued: the one wait, at its end (into page-locked memory where there is some)
+                    if len(req) > 2 and req[2] is not None:
+                        req[2].copy_(req[1], non_blocking=True)
+                        torch.cuda.current_stream().synchronize()
+                        val = req[2].numpy().copy()
+                    else:
+                        val = req[1].cpu().numpy()
                     if clock is not None:
                         clock["enqueue_s"] = clock.get("enqueue_s", 0.0) + (t_wait - t_begin)
                         clock["wait_s"] = clock.get("wait_s", 0.0) + (time.perf_counter() - t_wait)
@@ -293,6 +299,12 @@ class ShardedFilter:
         self.t_late = torch.zeros(W * (W + 1) + 1, dtype=torch.int64, device=dev)    # what the host reads: the gathered counts ...
         self.t_all_counts = self.t_late[:W * (W + 1)]
         self.t_flag = self.t_late[W * (W + 1):]                                      # ... and the fixed exchange's flag
+        self.h_late = None
+        if dev.type == "cuda":
+            try:
+                self.h_late = torch.empty(W * (W + 1) + 1, dtype=torch.int64).pin_memory()
+            except RuntimeError:
+                self.h_late = None
         self.fixed_rows = int(self.FIXED_ROWS)
         if self.fixed_rows:
             self.t_blocks_send = torch.zeros((W * self.fixed_rows, 6), dtype=torch.float64, device=dev)
@@ -329,7 +341,7 @@ class ShardedFilter:
             yield ("all_to_all_fixed", self.t_blocks_recv, self.t_blocks_send)
             ctx.dshard_unpack_fixed(self.t_blocks_recv.data_ptr(), self.t_all_counts.data_ptr(), world, rank,
                                     self.fixed_rows, r, self.t_flag.data_ptr())
-            late = yield ("read_late", self.t_late)
+            late = yield ("read_late", self.t_late, self.h_late)
             flag = int(late[-1])
             counts = late[:-1].reshape(world, world + 1)
             if flag:
