@@ -57,7 +57,8 @@ constexpr int kWavesPerBlock = MCL_WPB;
 constexpr int kGroup = MCL_GROUP;   // beams examined per step of the matching loop
 constexpr int kCapSpan = 16;
 constexpr int cap_buckets(int cap) { int n = 1; while (n < 2 * cap) n <<= 1; return n; }
-constexpr int kEdgeQueue = 64;        // cells on a sector edge that a particle can park (interval path); more: the particle is done entry by entry
+constexpr int kEdgeQueue = 32;        // cells on a sector edge that a particle can park (interval path); more: the particle is done entry by entry
+constexpr int kEdgeQueueWide = 64;    // ... in the interval-only kernel, whose queue also takes the unused part of the ring (see edgeq)
 constexpr int kSubLists = 64;         // the list of left-over particles is kept as this many lists with a counter each (blocks b, b + 64, ... share one)
 constexpr int kFiled = 16;            // particles an interval-only wave notes before it appends them to the list in one go
 constexpr int kSeamSlots = 64;        // beams near the seam of the bearings whose cells there are asked one by one (interval-only kernel, headings outside the circular range)
@@ -413,7 +414,12 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
   unsigned long long* const emin = rmin + NXQ;                     // GRID: per entry, what only its own angle let in
   unsigned long long* const aux = s_aux_all + (size_t)wv * RS;     // STAGE: hit cell per entry; PRODUCT: p_k in caller order
   unsigned int* const ring = s_walk_all + (size_t)wv * kWaveScratch;   // [128] cells waiting to be matched
-  unsigned long long* const edgeq = reinterpret_cast<unsigned long long*>(ring + 128);   // [kEdgeQueue] edge << 32 | cell
+  // [EQ] edge << 32 | cell.  The interval-only kernel keeps no ring of cells: of the ring's 128 words it uses 48 for its
+  // results (outbuf, outidx), and its queue -- which the second pass fills with the cells at the seam of the bearings
+  // as well -- starts behind them and runs on through the other kernels' queue: 72 entries' room for 64.
+  constexpr int EQ = IVONLY ? kEdgeQueueWide : kEdgeQueue;
+  static_assert(48 + 2 * kEdgeQueueWide <= 128 + 2 * kEdgeQueue, "the wide queue ends where the narrow one does, at the latest");
+  unsigned long long* const edgeq = reinterpret_cast<unsigned long long*>(ring + (IVONLY ? 48 : 128));
   unsigned int* const edge_cnt = ring + 128 + 2 * kEdgeQueue;
   // IVONLY: the particles this wave leaves to the launch that follows are noted here and appended to the list kFiled
   // at a time -- one atomic per wave and batch, not per particle: a cloud whose headings are all outside the interval
@@ -690,7 +696,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
             unsigned int E = (unsigned int)(at_lower ? m : (m + 1 == IVN ? 0 : m + 1));
             if constexpr (QK) { if (fabsf(aaf) < seam_w) E = 0x80000000u | (unsigned int)m; }   // a cell at the seam: its interval
             const unsigned int pos = atomicAdd(edge_cnt, 1u);
-            if (pos < (unsigned int)kEdgeQueue) edgeq[pos] = ((unsigned long long)E << 32) | e;
+            if (pos < (unsigned int)EQ) edgeq[pos] = ((unsigned long long)E << 32) | e;
             else lane_redo = true;
             lane_parked = true;
           }
@@ -944,7 +950,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
           }
         }
         if (nq > 0) {
-          if (lane < nq && lane < kEdgeQueue) {
+          if (lane < nq && lane < EQ) {
             const unsigned long long q = edgeq[lane];
             const unsigned int e = (unsigned int)q;
             const int E = (int)(q >> 32);
