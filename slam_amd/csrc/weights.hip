@@ -713,12 +713,24 @@ __global__ __launch_bounds__(kScanBlock) void normalise_classify_shard_kernel(do
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double t = 0.0, below = 0.0;
-    int i = 0;
-    for (int r = 0; r < lay.world; ++r) {
-      if (r == lay.rank) below = t;
-      for (int j = 0; j < lay.nchunks[r]; ++j) t = t + s_chunk[i++];
-    }
+    // strictly left to right, eight LDS reads in flight ahead of their eight additions (at eight ranks there are a
+    // thousand chunk sums: one read's latency per addition would cost every block tens of microseconds)
+    auto run_on = [&](double t, int from, int to) {
+      int i = from;
+      for (; i + 8 <= to; i += 8) {
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = s_chunk[i + j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t = t + v[j];
+      }
+      for (; i < to; ++i) t = t + s_chunk[i];
+      return t;
+    };
+    int mine = 0;
+    for (int r = 0; r < lay.rank; ++r) mine += lay.nchunks[r];
+    const double below = run_on(0.0, 0, mine);
+    const double t = run_on(below, mine, at);
     s_tb[0] = t;
     s_tb[1] = below / t;
   }
