@@ -1589,7 +1589,7 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
       // grid is sized for every particle and the blocks beyond the list leave at once -- a short list is bound by
       // the latency of one particle per wave, so it wants many waves rather than long strides)
       int64_t blocks_q = (n + wpb - 1) / wpb;
-      const int64_t cap_q = 3584 * kWavesPerBlock / wpb;                    // (as below)
+      const int64_t cap_q = 3584 * kWavesPerBlock / wpb;                    // (as below; 896 … 14336 blocks measured: 0.083, 0.066, 0.063, 0.066, 0.069 ms for the two launches)
       if (blocks_q > cap_q) blocks_q = cap_q;
       blocks_q = (blocks_q + kSubLists - 1) / kSubLists * kSubLists;
       if (every) {
