@@ -327,19 +327,22 @@ int mclhip_dshard_unpack_resample(mclhip_ctx* ctx, const void* d_rows, int64_t L
 /* The same exchange without a host read in the step (no counterpart in the reference, which is one process).
  * Every pair of ranks exchanges a block of cap_rows rows whatever it holds -- d_blocks [world][cap_rows][6] doubles,
  * sent and received with equal splits -- and the rows a rank draws from itself stay in a buffer of the context.
- *   mclhip_dshard_pack_fixed    after mclhip_dshard_finalize: the drawn rows for rank d into block d (what exceeds
- *                               cap_rows is left out), the rank's own into the context's buffer
- *   mclhip_dshard_unpack_fixed  d_blocks: the received blocks (block s from rank s); d_all_counts [world][world + 1]:
- *                               every rank's d_counts_out, gathered, still on the device.  *d_flag_out (device memory)
+ *   mclhip_dshard_pack_fixed    after mclhip_dshard_finalize and the gathering of every rank's d_counts_out into
+ *                               d_all_counts [world][world + 1] (still on the device): the drawn rows for rank d into
+ *                               block d (what exceeds cap_rows is left out), the rank's own into the context's buffer;
+ *                               *d_flag_out (device memory) as below -- known here already, so that a caller can copy
+ *                               it to the host behind this call and wait for that copy instead of for the step's end
+ *   mclhip_dshard_unpack_fixed  d_blocks: the received blocks (block s from rank s).  *d_flag_out
  *                               = 0: the local positions have been resampled as by mclhip_dshard_unpack_resample;
  *                               1: some rank's record exchange overflowed; 2: some pair has more rows than cap_rows --
  *                               then NOTHING was resampled.  The flag is the same on every rank (it is formed from the
- *                               whole matrix); the caller reads it after the step has been enqueued, and on 1 or 2
+ *                               whole matrix); the caller reads it once the step has been enqueued, and on 1 or 2
  *                               calls mclhip_dshard_unpack_undo (the call has swapped the context's particle arrays
  *                               on the host as every resampling call does) and finishes the step with exact counts
  *                               (mclhip_dshard_pack / _unpack_resample) or on the host path.
  * Neither call waits. */
-int mclhip_dshard_pack_fixed(mclhip_ctx* ctx, int world, int rank, int64_t cap_rows, void* d_blocks);
+int mclhip_dshard_pack_fixed(mclhip_ctx* ctx, int world, int rank, int64_t cap_rows, void* d_blocks,
+                             const int64_t* d_all_counts, int64_t* d_flag_out);
 int mclhip_dshard_unpack_fixed(mclhip_ctx* ctx, const void* d_blocks, const int64_t* d_all_counts, int world, int rank,
                                int64_t cap_rows, double r, int64_t* d_flag_out);
 int mclhip_dshard_unpack_undo(mclhip_ctx* ctx);

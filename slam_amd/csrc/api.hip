@@ -1322,18 +1322,19 @@ int mclhip_dshard_unpack_resample(mclhip_ctx* c, const void* d_rows, int64_t L, 
   return MCLHIP_OK;
 }
 
-int mclhip_dshard_pack_fixed(mclhip_ctx* c, int world, int rank, int64_t cap_rows, void* d_blocks) {
+int mclhip_dshard_pack_fixed(mclhip_ctx* c, int world, int rank, int64_t cap_rows, void* d_blocks,
+                             const int64_t* d_all_counts, int64_t* d_flag_out) {
   MCL_TRY(use(c));
   MCL_TRY(need(c, false, false, true));
-  if (!d_blocks || world < 1 || world > 64 || rank < 0 || rank >= world || cap_rows < 1)
-    return fail(c, MCLHIP_E_ARG, "d_blocks NULL, world outside 1..64, rank outside the world or cap_rows < 1");
+  if (!d_blocks || !d_all_counts || !d_flag_out || world < 1 || world > 64 || rank < 0 || rank >= world || cap_rows < 1)
+    return fail(c, MCLHIP_E_ARG, "NULL argument, world outside 1..64, rank outside the world or cap_rows < 1");
   if (c->M + 64 > c->rows_self_cap) {
     MCL_HIP(c, hipStreamSynchronize(c->stream));
     MCL_TRY(dev_alloc(c, &c->rows_self, (size_t)(c->M + 64) * 6 * sizeof(double)));
     c->rows_self_cap = c->M + 64;
   }
   span_begin(c, c->spans, 2);
-  MCL_TRY(launch_pack_fixed(c, world, rank, cap_rows, (double*)d_blocks, (double*)c->rows_self));
+  MCL_TRY(launch_pack_fixed(c, world, rank, cap_rows, (double*)d_blocks, (double*)c->rows_self, d_all_counts, d_flag_out));
   span_end(c, c->spans);
   return MCLHIP_OK;
 }

@@ -1232,14 +1232,42 @@ __global__ __launch_bounds__(256) void unpack_drawn_kernel(const double* __restr
 // packed into a buffer of the context's own.  What a block holds is known from the gathered counts, on the device;
 // whether every block was large enough is known there too, and the host looks at that flag only after the step has
 // been enqueued to its end (nothing is resampled when it is set: the step is then finished with exact counts).
+// 0 fine, 1 a rank's record merge overflowed (it planned nothing), 2 some pair's rows exceed `cap`: from the whole
+// gathered matrix (all_counts[s][d]: rows rank s has for rank d; all_counts[s][world]: rank s planned nothing), so the
+// same on every rank.  By a whole block of 256 threads; s_flag: 256 ints of LDS.
+__device__ inline int exchange_flag(const int64_t* __restrict__ all_counts, int world, int64_t cap, int* s_flag) {
+  int f = 0;
+  for (int k = threadIdx.x; k < world * (world + 1); k += blockDim.x) {
+    const int s_ = k / (world + 1), d = k - s_ * (world + 1);
+    const int64_t v = all_counts[k];
+    if (d == world) { if (v != 0) f = 1; }
+    else if (s_ != d && v > cap && f == 0) f = 2;
+  }
+  s_flag[threadIdx.x] = f;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int g = 0;
+    for (int k = 0; k < (int)blockDim.x; ++k) g = (s_flag[k] == 1 || g == 1) ? 1 : (s_flag[k] == 2 ? 2 : g);
+    s_flag[0] = g;
+  }
+  __syncthreads();
+  return s_flag[0];
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void pack_fixed_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ th,
                                                          const double* __restrict__ w, const double* __restrict__ cdf,
                                                          const int64_t* __restrict__ G, const unsigned int* __restrict__ S,
                                                          int64_t n, int64_t first_index, int world, int rank, int64_t cap,
                                                          const int64_t* __restrict__ slices, double* __restrict__ dst,
-                                                         double* __restrict__ self_dst) {
+                                                         double* __restrict__ self_dst,
+                                                         const int64_t* __restrict__ all_counts, int64_t* __restrict__ flag_out) {
   __shared__ int64_t s_sl[4 * 64];
+  __shared__ int s_flag[256];
+  if (blockIdx.x == 0) {   // the exchange's flag, as early as it can be known: the host waits for this, not for the step's end
+    const int f = exchange_flag(all_counts, world, cap, s_flag);
+    if (threadIdx.x == 0) flag_out[0] = f;
+  }
   for (int k = threadIdx.x; k < 4 * world; k += blockDim.x) s_sl[k] = slices[k];
   __syncthreads();
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1277,31 +1305,17 @@ __global__ __launch_bounds__(256) void unpack_fixed_kernel(const double* __restr
                                                            double* __restrict__ w2, int64_t* __restrict__ idx) {
   __shared__ int64_t s_off[66];
   __shared__ int s_flag[256];
-  {
-    int f = 0;
-    for (int k = threadIdx.x; k < world * (world + 1); k += blockDim.x) {
-      const int s_ = k / (world + 1), d = k - s_ * (world + 1);
-      const int64_t v = all_counts[k];
-      if (d == world) { if (v != 0) f = 1; }
-      else if (s_ != d && v > cap && f == 0) f = 2;
-    }
-    s_flag[threadIdx.x] = f;
-  }
-  __syncthreads();
+  const int flag = exchange_flag(all_counts, world, cap, s_flag);
   if (threadIdx.x == 0) {
-    int f = 0;
-    for (int k = 0; k < 256; ++k) f = (s_flag[k] == 1 || f == 1) ? 1 : (s_flag[k] == 2 ? 2 : f);
     int64_t off = 0;
     for (int s_ = 0; s_ < world; ++s_) {
       s_off[s_] = off;
       off += all_counts[(size_t)s_ * (world + 1) + rank];
     }
     s_off[world] = off;
-    s_flag[0] = f;
-    if (blockIdx.x == 0) flag_out[0] = f;
+    if (blockIdx.x == 0) flag_out[0] = flag;
   }
   __syncthreads();
-  const int flag = s_flag[0];
   if (flag != 0) return;
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
@@ -1338,7 +1352,8 @@ __global__ __launch_bounds__(256) void unpack_fixed_kernel(const double* __restr
   w2[j] = sr[3];
 }
 
-int launch_pack_fixed(mclhip_ctx* c, int world, int rank, int64_t cap, double* d_dst, double* d_self) {
+int launch_pack_fixed(mclhip_ctx* c, int world, int rank, int64_t cap, double* d_dst, double* d_self,
+                      const int64_t* d_all_counts, int64_t* d_flag_out) {
   const int64_t n = c->M;
   const int a = c->cur;
   const unsigned g = (unsigned)((n + 255) / 256);
@@ -1347,11 +1362,11 @@ int launch_pack_fixed(mclhip_ctx* c, int world, int rank, int64_t cap, double* d
   if (c->dtype == MCLHIP_F32)
     hipLaunchKernelGGL(pack_fixed_kernel<float>, dim3(g), dim3(256), 0, c->stream, (const float*)c->px[a], (const float*)c->py[a],
                        (const float*)c->pth[a], (const double*)c->w[a], (const double*)c->cdf_exact, G, (const unsigned int*)c->fscan,
-                       n, c->first_index, world, rank, cap, slices, d_dst, d_self);
+                       n, c->first_index, world, rank, cap, slices, d_dst, d_self, d_all_counts, d_flag_out);
   else
     hipLaunchKernelGGL(pack_fixed_kernel<double>, dim3(g), dim3(256), 0, c->stream, (const double*)c->px[a], (const double*)c->py[a],
                        (const double*)c->pth[a], (const double*)c->w[a], (const double*)c->cdf_exact, G, (const unsigned int*)c->fscan,
-                       n, c->first_index, world, rank, cap, slices, d_dst, d_self);
+                       n, c->first_index, world, rank, cap, slices, d_dst, d_self, d_all_counts, d_flag_out);
   MCL_HIP(c, hipGetLastError());
   return MCLHIP_OK;
 }
