@@ -507,7 +507,8 @@ int mclhip_fs_dshard_unpack(mclhip_ctx* ctx, const void* d_rows, const void* d_f
  *            launch (the count the host last saw: written behind that launch, never waited for);
  *        7 = likewise, what the first launch left over: the same number, unless the interval kernel made a second
  *            pass over that list in between (evenly spaced beams; headings outside the range in which the
- *            reference's predicate is the circular one; see MCLHIP_EVERY_HEADING in the integration notes).
+ *            reference's predicate is the circular one; the environment variable MCLHIP_EVERY_HEADING, read when a
+ *            context is created, forces that pass with 1 and forbids it with 0).
  * on: 0 off, 1 every group, 2 the sector-query kernel only (two events per step instead of six: an event between
  * two kernels costs a few microseconds of idle GPU).  Enabling resets the accumulators. */
 int mclhip_timing_enable(mclhip_ctx* ctx, int on);

@@ -28,7 +28,7 @@ Two figures beside the issue fraction say how much of the issued work is needed 
   * the algorithmic instruction floor: the fewest vector wave-instructions a particle needs on this hardware if
     every lane of every instruction did needed work --
         ALGO_PER_PARTICLE + ALGO_PER_CELL x cells_in_range / 64 + ALGO_PER_BEAM x beams / 64
-    (the constants are counted out instruction by instruction in the design notes) -- priced with the kernel's
+    (the constants are counted out below, beside their definitions) -- priced with the kernel's
     average issue cost; `frac_of_algorithmic_floor` = that time / the measured kernel time.
 """
 import hashlib
@@ -37,7 +37,7 @@ import os
 import re
 import sys
 
-# fewest vector instructions (per lane that does needed work): see the design notes, sector query
+# fewest vector instructions (per lane that does needed work) of the interval-only sector-query kernel
 ALGO_PER_CELL = 41       # unpack + float32 coordinates and differences 4, exact float64 squared distance 6, range test 1,
                          # float32 bearing 20, place on the circle of intervals and distance to its edges 9, LDS address 1
 ALGO_PER_BEAM = 30       # four float64 minima over the five intervals of a sector, root, the float32 mixture with two
