@@ -260,6 +260,7 @@ struct mclhip_ctx {
   void* g_bases = nullptr;
   void* rows_send = nullptr; int64_t rows_send_cap = 0;   // packed rows handed to / received from the exchange
   void* rows_recv = nullptr; int64_t rows_recv_cap = 0;
+  int64_t* draw_ends = nullptr;      // where the last draw plan left the draw ends (c->kscan or c->cdf_approx)
   bool dshard_tiles_ready = false;   // c->cdf_approx holds the tile sums of launch_dshard_weights
   void* rows_self = nullptr; int64_t rows_self_cap = 0;   // the fixed-block exchange: the rows a rank draws from itself
   int64_t* sel = nullptr; int64_t sel_cap = 0;            // local row behind every place of the send buffer (drawn-row exchange)

@@ -1236,22 +1236,16 @@ __global__ __launch_bounds__(256) void unpack_drawn_kernel(const double* __restr
 // gathered matrix (all_counts[s][d]: rows rank s has for rank d; all_counts[s][world]: rank s planned nothing), so the
 // same on every rank.  By a whole block of 256 threads; s_flag: 256 ints of LDS.
 __device__ inline int exchange_flag(const int64_t* __restrict__ all_counts, int world, int64_t cap, int* s_flag) {
-  int f = 0;
+  int f1 = 0, f2 = 0;
   for (int k = threadIdx.x; k < world * (world + 1); k += blockDim.x) {
     const int s_ = k / (world + 1), d = k - s_ * (world + 1);
     const int64_t v = all_counts[k];
-    if (d == world) { if (v != 0) f = 1; }
-    else if (s_ != d && v > cap && f == 0) f = 2;
+    if (d == world) { if (v != 0) f1 = 1; }
+    else if (s_ != d && v > cap) f2 = 1;
   }
-  s_flag[threadIdx.x] = f;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int g = 0;
-    for (int k = 0; k < (int)blockDim.x; ++k) g = (s_flag[k] == 1 || g == 1) ? 1 : (s_flag[k] == 2 ? 2 : g);
-    s_flag[0] = g;
-  }
-  __syncthreads();
-  return s_flag[0];
+  (void)s_flag;
+  const int any1 = __syncthreads_or(f1), any2 = __syncthreads_or(f2);
+  return any1 ? 1 : (any2 ? 2 : 0);
 }
 
 template <typename T>
@@ -1357,7 +1351,7 @@ int launch_pack_fixed(mclhip_ctx* c, int world, int rank, int64_t cap, double* d
   const int64_t n = c->M;
   const int a = c->cur;
   const unsigned g = (unsigned)((n + 255) / 256);
-  const int64_t* G = reinterpret_cast<const int64_t*>(c->kscan);
+  const int64_t* G = c->draw_ends;
   const int64_t* slices = c->small_i + 8;
   if (c->dtype == MCLHIP_F32)
     hipLaunchKernelGGL(pack_fixed_kernel<float>, dim3(g), dim3(256), 0, c->stream, (const float*)c->px[a], (const float*)c->py[a],
@@ -1473,20 +1467,67 @@ __global__ __launch_bounds__(256) void merge_replay_kernel(const unsigned long l
   if (threadIdx.x < 64) replay_body(g_records, (unsigned int)meta[0], bases, threadIdx.x);
 }
 
-// finalize_cdf_kernel and draw_ends_kernel in one launch
-__global__ void finalize_draw_kernel(const unsigned long long* ks, const unsigned int* __restrict__ fs,
-                                     const RunBase* __restrict__ bases, int64_t n, double* __restrict__ cdf,
-                                     const unsigned long long* __restrict__ off_ptr, int64_t m_total, double r, int last_rank,
-                                     int64_t* G) {   // (G is ks's own memory: every thread reads its element before it writes it)
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// finalize_cdf_kernel, draw_ends_kernel and the first pass of the scan of the drawn flags in one launch: a thread per
+// element (coalesced), a block per 256; exact running sums -> cdf, draw ends -> G (an array of its own: a block's first
+// flag needs the draw end of the element before it, which this block forms once more from that element's integer
+// prefix), the number of drawn rows of the block -> blk_count
+constexpr int kDrawBlock = 256;
+__global__ __launch_bounds__(kDrawBlock) void finalize_draw_count_kernel(const unsigned long long* __restrict__ ks,
+                                                                         const unsigned int* __restrict__ fs,
+                                                                         const RunBase* __restrict__ bases, int64_t n,
+                                                                         double* __restrict__ cdf,
+                                                                         const unsigned long long* __restrict__ off_ptr,
+                                                                         int64_t m_total, double r, int last_rank,
+                                                                         int64_t* __restrict__ G, unsigned int* __restrict__ blk_count) {
+  __shared__ int64_t s_g[kDrawBlock];
+  __shared__ unsigned int s_cnt[kDrawBlock / 64];
   const unsigned long long P_off = off_ptr[1];
   const unsigned int F_off = (unsigned int)off_ptr[2];
-  const RunBase b = bases[F_off + fs[i] - 1];
-  const unsigned long long k = ks[i];
-  const double ci = b.c + (double)(P_off + k - b.P) * ldexp(1.0, b.e - 52);  // exact (see finalize_cdf_kernel)
-  cdf[i] = ci;
-  G[i] = (last_rank && i == n - 1) ? m_total : first_above(ci, m_total, r);   // (overwrites ks[i]: read above)
+  auto end_of = [&](int64_t i, bool store) -> int64_t {
+    const RunBase b = bases[F_off + fs[i] - 1];
+    const double ci = b.c + (double)(P_off + ks[i] - b.P) * ldexp(1.0, b.e - 52);  // exact (see finalize_cdf_kernel)
+    if (store) cdf[i] = ci;
+    return (last_rank && i == n - 1) ? m_total : first_above(ci, m_total, r);
+  };
+  const int64_t i = (int64_t)blockIdx.x * kDrawBlock + threadIdx.x;
+  int64_t g = 0;
+  if (i < n) { g = end_of(i, true); G[i] = g; }
+  s_g[threadIdx.x] = g;
+  __syncthreads();
+  unsigned int flag = 0u;
+  if (i < n) {
+    int64_t before = 0;
+    if (threadIdx.x > 0) before = s_g[threadIdx.x - 1];
+    else if (i > 0) before = end_of(i - 1, false);
+    flag = (i == 0 || g > before) ? 1u : 0u;                 // DrawnFlagLoader
+  }
+  const unsigned int wave_cnt = (unsigned int)__popcll(__ballot(flag != 0u));
+  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = wave_cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) blk_count[blockIdx.x] = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+}
+
+// second pass: S[i] = number of drawn rows among local rows 0..i; every block adds the earlier blocks' counts for itself
+__global__ __launch_bounds__(kDrawBlock) void drawn_scan_kernel(const int64_t* __restrict__ G, int64_t n,
+                                                                const unsigned int* __restrict__ blk_count,
+                                                                unsigned int* __restrict__ S) {
+  __shared__ unsigned int s_red[kDrawBlock / 64];
+  __shared__ unsigned int s_wave[kDrawBlock / 64];
+  unsigned int part = 0u;
+  for (int j = threadIdx.x; j < (int)blockIdx.x; j += kDrawBlock) part += blk_count[j];
+  for (int d = 32; d >= 1; d >>= 1) part += (unsigned int)__shfl_xor((int)part, d, 64);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = part;
+  const int64_t i = (int64_t)blockIdx.x * kDrawBlock + threadIdx.x;
+  DrawnFlagLoader fl{G};
+  const unsigned int f = (i < n) ? fl(i) : 0u;
+  const unsigned long long m = __ballot(f != 0u);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) s_wave[wv] = (unsigned int)__popcll(m);
+  __syncthreads();
+  unsigned int off = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+  for (int k = 0; k < wv; ++k) off += s_wave[k];
+  const unsigned int incl = off + (unsigned int)__popcll(m & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull)));
+  if (i < n) S[i] = incl;
 }
 
 int launch_dshard_finalize(mclhip_ctx* c, const void* d_all_rec, const ShardLayout& lay, int cap, double r,
@@ -1496,10 +1537,21 @@ int launch_dshard_finalize(mclhip_ctx* c, const void* d_all_rec, const ShardLayo
   const unsigned g = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(merge_replay_kernel, dim3(1), dim3(256), 0, c->stream, (const unsigned long long*)d_all_rec,
                      lay.world, lay.rank, cap, (IrrRecord*)c->g_records, meta, (RunBase*)c->g_bases);
-  hipLaunchKernelGGL(finalize_draw_kernel, dim3(g), dim3(256), 0, c->stream, (const unsigned long long*)c->kscan, c->fscan,
-                     (const RunBase*)c->g_bases, n, c->cdf_exact, (const unsigned long long*)meta, c->m_total, r,
-                     lay.rank == lay.world - 1 ? 1 : 0, reinterpret_cast<int64_t*>(c->kscan));
-  return launch_plan_drawn(c, lay, r, d_counts, meta, true);
+  // (the draw ends in an array of their own -- the tile sums' of launch_dshard_weights, spent by now --, the scan of the
+  // drawn flags over the record counts, which the running sums have consumed)
+  int64_t* G = reinterpret_cast<int64_t*>(c->cdf_approx);
+  unsigned int* blk_count = reinterpret_cast<unsigned int*>(c->bases);   // (one per 256 rows; the single-GPU replay's bases are not in use on this path)
+  hipLaunchKernelGGL(finalize_draw_count_kernel, dim3(g), dim3(kDrawBlock), 0, c->stream, (const unsigned long long*)c->kscan,
+                     (const unsigned int*)c->fscan, (const RunBase*)c->g_bases, n, c->cdf_exact, (const unsigned long long*)meta,
+                     c->m_total, r, lay.rank == lay.world - 1 ? 1 : 0, G, blk_count);
+  hipLaunchKernelGGL(drawn_scan_kernel, dim3(g), dim3(kDrawBlock), 0, c->stream, (const int64_t*)G, n,
+                     (const unsigned int*)blk_count, c->fscan);
+  c->draw_ends = G;
+  int64_t* slices = c->small_i + 8;
+  hipLaunchKernelGGL(plan_slices_kernel, dim3(1), dim3(64), 0, c->stream, (const int64_t*)G, (const unsigned int*)c->fscan, n, lay,
+                     meta, slices, d_counts);
+  MCL_HIP(c, hipGetLastError());
+  return MCLHIP_OK;
 }
 
 // which local rows are drawn at all, and by the positions of which rank: only those travel.  Needs the exact running
@@ -1511,6 +1563,7 @@ int launch_plan_drawn(mclhip_ctx* c, const ShardLayout& lay, double r, int64_t* 
   const unsigned g = (unsigned)((n + 255) / 256);
   const int ntile = (int)((n + kScanTile - 1) / kScanTile);
   int64_t* G = reinterpret_cast<int64_t*>(c->kscan);           // the integer prefixes are spent once the running sums exist
+  c->draw_ends = G;
   unsigned int* S = c->fscan;                                  // likewise the record counts
   if (!ends_done)
     hipLaunchKernelGGL(draw_ends_kernel, dim3(g), dim3(256), 0, c->stream, (const double*)c->cdf_exact, n, c->m_total, r,
@@ -1534,7 +1587,7 @@ int launch_pack_drawn(mclhip_ctx* c, int world, double* d_dst, int64_t* d_sel) {
   const int64_t n = c->M;
   const int a = c->cur;
   const unsigned g = (unsigned)((n + 255) / 256);
-  const int64_t* G = reinterpret_cast<const int64_t*>(c->kscan);
+  const int64_t* G = c->draw_ends;
   const int64_t* slices = c->small_i + 8;
   if (c->dtype == MCLHIP_F32)
     hipLaunchKernelGGL(pack_drawn_kernel<float>, dim3(g), dim3(256), 0, c->stream, (const float*)c->px[a], (const float*)c->py[a],
