@@ -1132,26 +1132,43 @@ __global__ void plan_slices_kernel(const int64_t* __restrict__ G, const unsigned
                                    ShardLayout lay, const unsigned long long* __restrict__ meta,
                                    int64_t* __restrict__ slices, int64_t* __restrict__ counts) {
   __shared__ int64_t s_cnt[64];
-  const int d = threadIdx.x;
-  if (d < lay.world) {
-    auto first_row_above = [&](int64_t x) -> int64_t {      // first j with G[j] > x (n if none)
-      int64_t lo = 0, hi = n;
-      while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (G[mid] > x) hi = mid; else lo = mid + 1;
+  // a wavefront per destination: the searches probe 64 places at a time (four rounds of dependent reads for a million
+  // rows instead of twenty)
+  const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  auto first_row_above = [&](int64_t x) -> int64_t {        // first j with G[j] > x (n if none); wave-uniform
+    int64_t lo = 0, hi = n;                                  // the answer lies in [lo, hi]
+    while (hi - lo > 64) {
+      const int64_t step = (hi - lo + 63) / 64;
+      const int64_t p = lo + (int64_t)lane * step;
+      const bool in = p < hi;
+      const unsigned long long m = __ballot(in && G[p] > x);
+      const unsigned long long valid = __ballot(in);
+      if (m == 0ull) {
+        lo = lo + (int64_t)(63 - __clzll(valid)) * step + 1;  // beyond the last place probed
+      } else {
+        const int f = __ffsll((long long)m) - 1;
+        hi = lo + (int64_t)f * step;
+        if (f > 0) lo = lo + (int64_t)(f - 1) * step + 1;
       }
-      return lo;
-    };
+    }
+    const int64_t p = lo + lane;
+    const unsigned long long m = __ballot(p < hi && G[p] > x);
+    return m == 0ull ? hi : lo + (__ffsll((long long)m) - 1);
+  };
+  for (int d = threadIdx.x >> 6; d < lay.world; d += nw) {
     const int64_t jl = first_row_above(lay.first[d]);
     int64_t jh = first_row_above(lay.first[d + 1] - 1);      // G[j-1] <= last position  <=>  j <= that row
     if (jh > n - 1) jh = n - 1;
     int64_t cnt = 0;
     if (lay.first[d + 1] > lay.first[d] && jl <= jh) cnt = (int64_t)S[jh] - (jl > 0 ? (int64_t)S[jl - 1] : 0);
-    slices[4 * d] = jl; slices[4 * d + 1] = jh; slices[4 * d + 2] = cnt;
-    s_cnt[d] = cnt;
-    counts[d] = cnt;
+    if (lane == 0) {
+      slices[4 * d] = jl; slices[4 * d + 1] = jh; slices[4 * d + 2] = cnt;
+      s_cnt[d] = cnt;
+      counts[d] = cnt;
+    }
   }
   __syncthreads();
+  const int d = threadIdx.x;
   if (d == 0) {
     // With exact running sums the draw ends ascend and the slices hold every local row once and the rows at the rank
     // boundaries twice: at most n + world rows, which is what the callers' send buffers hold.  After a record merge
@@ -1548,7 +1565,7 @@ int launch_dshard_finalize(mclhip_ctx* c, const void* d_all_rec, const ShardLayo
                      (const unsigned int*)blk_count, c->fscan);
   c->draw_ends = G;
   int64_t* slices = c->small_i + 8;
-  hipLaunchKernelGGL(plan_slices_kernel, dim3(1), dim3(64), 0, c->stream, (const int64_t*)G, (const unsigned int*)c->fscan, n, lay,
+  hipLaunchKernelGGL(plan_slices_kernel, dim3(1), dim3(64 * (lay.world < 16 ? lay.world : 16)), 0, c->stream, (const int64_t*)G, (const unsigned int*)c->fscan, n, lay,
                      meta, slices, d_counts);
   MCL_HIP(c, hipGetLastError());
   return MCLHIP_OK;
@@ -1576,7 +1593,7 @@ int launch_plan_drawn(mclhip_ctx* c, const ShardLayout& lay, double r, int64_t* 
   hipLaunchKernelGGL((scan_apply_kernel<unsigned int, DrawnFlagLoader, StoreU32>), dim3(ntile), dim3(kScanBlock), 0, c->stream, fl,
                      su, n, (const unsigned int*)c->blk_a);
   int64_t* slices = c->small_i + 8;                            // [4 * world] behind the merge's four words
-  hipLaunchKernelGGL(plan_slices_kernel, dim3(1), dim3(64), 0, c->stream, (const int64_t*)G, (const unsigned int*)S, n, lay,
+  hipLaunchKernelGGL(plan_slices_kernel, dim3(1), dim3(64 * (lay.world < 16 ? lay.world : 16)), 0, c->stream, (const int64_t*)G, (const unsigned int*)S, n, lay,
                      meta, slices, d_counts);
   MCL_HIP(c, hipGetLastError());
   return MCLHIP_OK;
