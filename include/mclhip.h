@@ -330,8 +330,10 @@ int mclhip_dshard_unpack_resample(mclhip_ctx* ctx, const void* d_rows, int64_t L
  *   mclhip_dshard_pack_fixed    after mclhip_dshard_finalize and the gathering of every rank's d_counts_out into
  *                               d_all_counts [world][world + 1] (still on the device): the drawn rows for rank d into
  *                               block d (what exceeds cap_rows is left out), the rank's own into the context's buffer;
- *                               *d_flag_out (device memory) as below -- known here already, so that a caller can copy
- *                               it to the host behind this call and wait for that copy instead of for the step's end
+ *                               *d_flag_out (device memory) as below -- known here already: with h_late_out (page-locked
+ *                               host memory the device can write, [world * (world + 1) + 1] words, or NULL) the kernel
+ *                               stores the gathered counts and the flag there itself, and a caller that records an
+ *                               event behind this call waits for that event instead of for the step's end
  *   mclhip_dshard_unpack_fixed  d_blocks: the received blocks (block s from rank s).  *d_flag_out
  *                               = 0: the local positions have been resampled as by mclhip_dshard_unpack_resample;
  *                               1: some rank's record exchange overflowed; 2: some pair has more rows than cap_rows --
@@ -342,7 +344,7 @@ int mclhip_dshard_unpack_resample(mclhip_ctx* ctx, const void* d_rows, int64_t L
  *                               (mclhip_dshard_pack / _unpack_resample) or on the host path.
  * Neither call waits. */
 int mclhip_dshard_pack_fixed(mclhip_ctx* ctx, int world, int rank, int64_t cap_rows, void* d_blocks,
-                             const int64_t* d_all_counts, int64_t* d_flag_out);
+                             const int64_t* d_all_counts, int64_t* d_flag_out, int64_t* h_late_out);
 int mclhip_dshard_unpack_fixed(mclhip_ctx* ctx, const void* d_blocks, const int64_t* d_all_counts, int world, int rank,
                                int64_t cap_rows, double r, int64_t* d_flag_out);
 int mclhip_dshard_unpack_undo(mclhip_ctx* ctx);

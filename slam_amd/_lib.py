@@ -84,7 +84,7 @@ PROTOTYPES = {
                                          C.c_void_p]),
     "mclhip_dshard_pack": (C.c_int, [_ctx_p, C.c_int, C.c_void_p]),
     "mclhip_dshard_unpack_resample": (C.c_int, [_ctx_p, C.c_void_p, C.c_int64, C.c_double]),
-    "mclhip_dshard_pack_fixed": (C.c_int, [_ctx_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mclhip_dshard_pack_fixed": (C.c_int, [_ctx_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mclhip_dshard_unpack_fixed": (C.c_int, [_ctx_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_double, C.c_void_p]),
     "mclhip_dshard_unpack_undo": (C.c_int, [_ctx_p]),
     "mclhip_get_indices": (C.c_int, [_ctx_p, _i64_p]),
@@ -472,9 +472,9 @@ class Context:
         self._ck(self.lib.mclhip_dshard_unpack_resample(self.h, C.c_void_p(d_rows), int(L), float(r)),
                  "mclhip_dshard_unpack_resample")
 
-    def dshard_pack_fixed(self, world, rank, cap_rows, d_blocks, d_all_counts, d_flag):
+    def dshard_pack_fixed(self, world, rank, cap_rows, d_blocks, d_all_counts, d_flag, h_late=None):
         self._ck(self.lib.mclhip_dshard_pack_fixed(self.h, int(world), int(rank), int(cap_rows), C.c_void_p(d_blocks),
-                                                   C.c_void_p(d_all_counts), C.c_void_p(d_flag)),
+                                                   C.c_void_p(d_all_counts), C.c_void_p(d_flag), C.c_void_p(h_late)),
                  "mclhip_dshard_pack_fixed")
 
     def dshard_unpack_fixed(self, d_blocks, d_all_counts, world, rank, cap_rows, r, d_flag):

@@ -1323,7 +1323,7 @@ int mclhip_dshard_unpack_resample(mclhip_ctx* c, const void* d_rows, int64_t L, 
 }
 
 int mclhip_dshard_pack_fixed(mclhip_ctx* c, int world, int rank, int64_t cap_rows, void* d_blocks,
-                             const int64_t* d_all_counts, int64_t* d_flag_out) {
+                             const int64_t* d_all_counts, int64_t* d_flag_out, int64_t* h_late_out) {
   MCL_TRY(use(c));
   MCL_TRY(need(c, false, false, true));
   if (!d_blocks || !d_all_counts || !d_flag_out || world < 1 || world > 64 || rank < 0 || rank >= world || cap_rows < 1)
@@ -1334,7 +1334,7 @@ int mclhip_dshard_pack_fixed(mclhip_ctx* c, int world, int rank, int64_t cap_row
     c->rows_self_cap = c->M + 64;
   }
   span_begin(c, c->spans, 2);
-  MCL_TRY(launch_pack_fixed(c, world, rank, cap_rows, (double*)d_blocks, (double*)c->rows_self, d_all_counts, d_flag_out));
+  MCL_TRY(launch_pack_fixed(c, world, rank, cap_rows, (double*)d_blocks, (double*)c->rows_self, d_all_counts, d_flag_out, h_late_out));
   span_end(c, c->spans);
   return MCLHIP_OK;
 }

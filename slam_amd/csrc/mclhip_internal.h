@@ -375,7 +375,7 @@ int launch_plan_drawn(mclhip_ctx* c, const ShardLayout& lay, double r, int64_t* 
 int launch_pack_drawn(mclhip_ctx* c, int world, double* d_dst, int64_t* d_sel);
 int launch_unpack_drawn(mclhip_ctx* c, const double* d_rows, int64_t L, double r, bool keep_pos);
 int launch_pack_fixed(mclhip_ctx* c, int world, int rank, int64_t cap, double* d_dst, double* d_self,
-                      const int64_t* d_all_counts, int64_t* d_flag_out);
+                      const int64_t* d_all_counts, int64_t* d_flag_out, int64_t* h_late);
 int launch_unpack_fixed(mclhip_ctx* c, const double* d_recv, const double* d_self, const int64_t* d_all_counts, int world,
                         int rank, int64_t cap, double r, int64_t* d_flag_out);
 int launch_pack_rows(mclhip_ctx* c, int64_t lo, int64_t hi, double* d_dst);

@@ -1272,12 +1272,17 @@ __global__ __launch_bounds__(256) void pack_fixed_kernel(const T* __restrict__ x
                                                          int64_t n, int64_t first_index, int world, int rank, int64_t cap,
                                                          const int64_t* __restrict__ slices, double* __restrict__ dst,
                                                          double* __restrict__ self_dst,
-                                                         const int64_t* __restrict__ all_counts, int64_t* __restrict__ flag_out) {
+                                                         const int64_t* __restrict__ all_counts, int64_t* __restrict__ flag_out,
+                                                         int64_t* __restrict__ host_late) {
   __shared__ int64_t s_sl[4 * 64];
   __shared__ int s_flag[256];
   if (blockIdx.x == 0) {   // the exchange's flag, as early as it can be known: the host waits for this, not for the step's end
     const int f = exchange_flag(all_counts, world, cap, s_flag);
     if (threadIdx.x == 0) flag_out[0] = f;
+    if (host_late) {       // ... and for this: counts and flag stored straight into the host's page-locked memory
+      for (int k = threadIdx.x; k < world * (world + 1); k += blockDim.x) host_late[k] = all_counts[k];
+      if (threadIdx.x == 0) host_late[world * (world + 1)] = f;
+    }
   }
   for (int k = threadIdx.x; k < 4 * world; k += blockDim.x) s_sl[k] = slices[k];
   __syncthreads();
@@ -1364,7 +1369,7 @@ __global__ __launch_bounds__(256) void unpack_fixed_kernel(const double* __restr
 }
 
 int launch_pack_fixed(mclhip_ctx* c, int world, int rank, int64_t cap, double* d_dst, double* d_self,
-                      const int64_t* d_all_counts, int64_t* d_flag_out) {
+                      const int64_t* d_all_counts, int64_t* d_flag_out, int64_t* h_late) {
   const int64_t n = c->M;
   const int a = c->cur;
   const unsigned g = (unsigned)((n + 255) / 256);
@@ -1373,11 +1378,11 @@ int launch_pack_fixed(mclhip_ctx* c, int world, int rank, int64_t cap, double* d
   if (c->dtype == MCLHIP_F32)
     hipLaunchKernelGGL(pack_fixed_kernel<float>, dim3(g), dim3(256), 0, c->stream, (const float*)c->px[a], (const float*)c->py[a],
                        (const float*)c->pth[a], (const double*)c->w[a], (const double*)c->cdf_exact, G, (const unsigned int*)c->fscan,
-                       n, c->first_index, world, rank, cap, slices, d_dst, d_self, d_all_counts, d_flag_out);
+                       n, c->first_index, world, rank, cap, slices, d_dst, d_self, d_all_counts, d_flag_out, h_late);
   else
     hipLaunchKernelGGL(pack_fixed_kernel<double>, dim3(g), dim3(256), 0, c->stream, (const double*)c->px[a], (const double*)c->py[a],
                        (const double*)c->pth[a], (const double*)c->w[a], (const double*)c->cdf_exact, G, (const unsigned int*)c->fscan,
-                       n, c->first_index, world, rank, cap, slices, d_dst, d_self, d_all_counts, d_flag_out);
+                       n, c->first_index, world, rank, cap, slices, d_dst, d_self, d_all_counts, d_flag_out, h_late);
   MCL_HIP(c, hipGetLastError());
   return MCLHIP_OK;
 }

@@ -209,13 +209,13 @@ def drive_exchanges(gen, torch, dist, stream, clock=None):
                         recv.copy_(host)
                     else:
                         dist.all_to_all_single(recv, send)
-                elif op == "copy_late":
-                    # what the host will read at the end of the step is known from here on: copied now, behind the kernel
-                    # that formed it, so that the wait below ends while the step's last kernels still run and the host
-                    # has the next step's first kernels enqueued before the GPU falls idle
+                elif op == "mark_late":
+                    # what the host will read at the end of the step has been stored into its page-locked memory by the
+                    # kernel just enqueued: an event behind that kernel, so that the wait below ends while the step's
+                    # last kernels still run and the host has the next step's first kernels enqueued before the GPU
+                    # falls idle
                     late_event = None
                     if len(req) > 2 and req[2] is not None:
-                        req[2].copy_(req[1], non_blocking=True)
                         late_event = torch.cuda.Event()
                         late_event.record()
                 elif op == "read_late":
@@ -332,7 +332,7 @@ class ShardedFilter:
         """Generator: enqueues this rank's work and yields the exchanges it needs, in order --
         ("all_reduce_max", t), ("all_gather", out, inp), ("all_gather_read", out, inp) -> numpy,
         ("all_to_all", send, send_counts, recv_counts) -> recv, ("all_to_all_fixed", recv, send) with equal blocks,
-        ("copy_late", t, pinned) (start copying t to the host), ("read_late", t, pinned) -> numpy.  Returns False if a rank had more
+        ("mark_late", t, pinned) (the kernel before it has stored t into the page-locked copy), ("read_late", t, pinned) -> numpy.  Returns False if a rank had more
         irregular records than the fixed exchange holds (the caller then finishes on the host path)."""
         ctx, rank, world, cap = self.b.ctx, self.rank, self.world, self.RECORD_CAP
         ctx.dshard_sample_max(v, omega, dt, alpha, z_meas, noise_ints, seed, self.mode, self.t_max.data_ptr())
@@ -347,8 +347,9 @@ class ShardedFilter:
             # was large enough; the host reads that, and the counts for its report, once the step is enqueued
             yield ("all_gather", self.t_all_counts, self.t_counts)
             ctx.dshard_pack_fixed(world, rank, self.fixed_rows, self.t_blocks_send.data_ptr(),
-                                  self.t_all_counts.data_ptr(), self.t_flag.data_ptr())
-            yield ("copy_late", self.t_late, self.h_late)          # flag and counts set off for the host here already
+                                  self.t_all_counts.data_ptr(), self.t_flag.data_ptr(),
+                                  self.h_late.data_ptr() if self.h_late is not None else None)
+            yield ("mark_late", self.t_late, self.h_late)          # flag and counts are on their way to the host here already
             yield ("all_to_all_fixed", self.t_blocks_recv, self.t_blocks_send)
             ctx.dshard_unpack_fixed(self.t_blocks_recv.data_ptr(), self.t_all_counts.data_ptr(), world, rank,
                                     self.fixed_rows, r, self.t_flag.data_ptr())

@@ -157,7 +157,7 @@ def _run_lockstep(torch, gens, settle):
             for d in range(W):
                 for s_ in range(W):
                     req[d][1][s_ * C:(s_ + 1) * C].copy_(req[s_][2][d * C:(d + 1) * C])
-        elif op == "copy_late":
+        elif op == "mark_late":
             pass
         elif op == "read_late":
             vals = [q[1].cpu().numpy() for q in req]
