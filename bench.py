@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--cpu-particles", type=int, default=8192, help="particles of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--host-collectives", action="store_true",
                     help="multi-rank step with the host combining the ranks' small results (default: device-driven)")
+    ap.add_argument("--direct-rccl", action="store_true",
+                    help="the device-driven step's collectives through librccl on the step's own stream (slam_amd/rccl_direct.py)")
     ap.add_argument("--rehearse-collectives", action="store_true",
                     help="run the multi-rank code path (RCCL group, cross-rank resampling) even with one rank")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -382,7 +384,8 @@ def main():
     alpha = [4, 2, 4, 4, 4, 2]
     filt = ShardedFilter(ctx, dist, rank, world, M, force_collectives=a.rehearse_collectives,
                          device_path=False if a.host_collectives else (True if (dist is not None and a.backend == "gloo"
-                                                                                    and world > 1) else None))
+                                                                                    and world > 1) else None),
+                         direct_rccl=True if a.direct_rccl else None)
 
     def one_step(t):
         if a.regime == "global":
@@ -470,6 +473,8 @@ def main():
                                            if getattr(filt, "fixed_rows", 0) else "in mid-step: the row counts of the all-to-all")
                           if filt.device_path else None,
                           "steps_finished_with_exact_counts": getattr(filt, "exact_exchanges", None),
+                          "collectives": ("librccl on the step's own stream" if getattr(filt, "direct", None) is not None
+                                          else "torch.distributed"),
                           "host_ms_per_step": ({k: 1e3 * v / max(getattr(filt, "steps_done", 0), 1)
                                                 for k, v in getattr(filt, "clock", {}).items()} or None),
                           "note": "only rows that some position draws travel (48 B each)"}

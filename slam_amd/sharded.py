@@ -155,18 +155,24 @@ def sequential_sum(values):
     return float(t)
 
 
-def drive_exchanges(gen, torch, dist, stream, clock=None):
+def drive_exchanges(gen, torch, dist, stream, clock=None, direct=None):
     """Serve the exchanges a device-step generator asks for with torch.distributed, on the step's stream.  Under RCCL
     the collectives read and write the device tensors; under gloo (ranks that share one GPU, in tests) the same calls
     run on host copies.  clock: a dict that receives the host's time per step -- "enqueue_s" up to the step's one wait,
-    "wait_s" in it -- for reports."""
+    "wait_s" in it -- for reports.  direct: a rccl_direct.DirectRccl, whose collectives are entries of the step's own stream
+    (the all-reduce, the all-gathers and the all-to-all of equal blocks; what else a step may need stays with torch)."""
     import time
     staged = dist.get_backend() != "nccl"
+    if staged:
+        direct = None
+    raw_stream = stream.cuda_stream if (direct is not None and stream is not None) else None
     t_begin = time.perf_counter()
     late_event = None
 
     def gather(out, inp):
-        if staged:
+        if direct is not None:
+            direct.all_gather(out, inp, raw_stream)
+        elif staged:
             host = torch.empty(out.shape, dtype=out.dtype)
             dist.all_gather_into_tensor(host, inp.cpu())
             out.copy_(host)
@@ -180,7 +186,9 @@ def drive_exchanges(gen, torch, dist, stream, clock=None):
                 op = req[0]
                 val = None
                 if op == "all_reduce_max":
-                    if staged:
+                    if direct is not None:
+                        direct.all_reduce_max_f64(req[1], raw_stream)
+                    elif staged:
                         host = req[1].cpu()
                         dist.all_reduce(host, op=dist.ReduceOp.MAX)
                         req[1].copy_(host)
@@ -203,7 +211,9 @@ def drive_exchanges(gen, torch, dist, stream, clock=None):
                         dist.all_to_all_single(val[:n_out], send[:n_in], [int(c) for c in rc], [int(c) for c in sc])
                 elif op == "all_to_all_fixed":
                     recv, send = req[1], req[2]            # equal blocks, one per rank
-                    if staged:
+                    if direct is not None:
+                        direct.all_to_all_equal(recv, send, raw_stream)
+                    elif staged:
                         host = torch.empty(recv.shape, dtype=recv.dtype)
                         dist.all_to_all_single(host, send.cpu())
                         recv.copy_(host)
@@ -246,7 +256,7 @@ class ShardedFilter:
     FIXED_ROWS = 2048
 
     def __init__(self, ctx_or_backend, dist, rank, world, m_local, weight_mode=_lib.W_LOG, force_collectives=False,
-                 device_path=None):
+                 device_path=None, direct_rccl=None):
         self.b = HipShardBackend(ctx_or_backend) if isinstance(ctx_or_backend, _lib.Context) else ctx_or_backend
         self.dist, self.rank, self.world, self.mode = dist, rank, world, weight_mode
         self.m_local = int(m_local)
@@ -267,12 +277,20 @@ class ShardedFilter:
                 device_path = (self.coll.backend == "nccl" and weight_mode == _lib.W_LOG and
                                isinstance(self.b, HipShardBackend))
             self.device_path = bool(device_path)
+            self.direct = None
             if self.device_path:
                 torch = self.coll.torch      # (the step's tensors live on the GPU whatever carries the collectives)
                 self._device_setup(torch, torch.device("cuda", torch.cuda.current_device()))
+                if direct_rccl is None:
+                    import os
+                    direct_rccl = os.environ.get("MCLHIP_RCCL_DIRECT", "0") == "1"
+                if direct_rccl and self.coll.backend == "nccl" and self.stream is not None:
+                    from .rccl_direct import DirectRccl
+                    self.direct = DirectRccl(torch, dist, rank, world)   # (collectives as entries of the step's own stream)
         else:
             self.sizes, self.firsts, self.m_total = [self.m_local], [0, self.m_local], self.m_local
             self.device_path = False
+            self.direct = None
 
     @classmethod
     def for_layout(cls, ctx, rank, sizes, weight_mode=_lib.W_LOG):
@@ -288,6 +306,7 @@ class ShardedFilter:
         self.firsts = [int(x) for x in np.concatenate([[0], np.cumsum(self.sizes)])]
         self.m_total = self.firsts[-1]
         self.last_idx, self.collective, self.device_path, self.coll = None, True, True, None
+        self.direct = None
         self.b.set_range(self.firsts[rank], self.m_total)
         self.chunk_cap = 8 * max((n + CHUNK - 1) // CHUNK for n in self.sizes)
         self._device_setup(torch, torch.device("cuda", torch.cuda.current_device()))
@@ -384,7 +403,7 @@ class ShardedFilter:
         return True
 
     def _drive(self, gen):
-        return drive_exchanges(gen, self._torch, self.dist, self.stream, self.clock)
+        return drive_exchanges(gen, self._torch, self.dist, self.stream, self.clock, self.direct)
 
     def step(self, v, omega, dt, alpha, z_meas, r, seed=0, noise_ints=None, want_idx=False):
         """r = (uniform draw) / M_total, identical on every rank."""

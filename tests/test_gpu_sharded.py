@@ -94,18 +94,42 @@ def test_two_ranks_equal_one_context(sizes, dtype, mode, devnoise):
     assert np.array_equal(np.concatenate([x["w"] for x in res]), wr)
 
 
-def _rccl_rank_fn(rank, world, dist, M, z_meas, device_path, record_cap=256):
+def _rccl_rank_fn(rank, world, dist, M, z_meas, device_path, record_cap=256, direct=False, steps=1):
     from slam_amd import _lib
     from slam_amd.sharded import ShardedFilter
     ShardedFilter.RECORD_CAP = record_cap
     X, noise, r = _inputs(M)
     ctx = _setup(_lib.F64)
     ctx.set_particles(X)
-    f = ShardedFilter(ctx, dist, 0, 1, M, weight_mode=_lib.W_LOG, force_collectives=True, device_path=device_path)
+    f = ShardedFilter(ctx, dist, 0, 1, M, weight_mode=_lib.W_LOG, force_collectives=True, device_path=device_path,
+                      direct_rccl=direct)
     assert f.coll.backend == "nccl" and f.coll.dev.type == "cuda" and f.device_path == device_path
-    f.step(1.5, 0.0, 0.1, ALPHA, z_meas, r, seed=99, noise_ints=noise, want_idx=True)
+    assert (f.direct is not None) == bool(direct)
+    for _ in range(steps):
+        f.step(1.5, 0.0, 0.1, ALPHA, z_meas, r, seed=99, noise_ints=noise, want_idx=True)
     Xo, wo, _ = ctx.get_particles()
     return {"idx": f.last_idx, "X": Xo, "w": wo, "total": f.total, "fallbacks": getattr(f, "fallbacks", 0)}
+
+
+def test_collectives_on_the_steps_own_stream_on_one_rank():
+    """The device-driven step with its collectives called through librccl on the step's own stream (a communicator of
+    one rank beside torch's): bit-equal to the fused step, over one step and over three."""
+    from slam_amd import _lib
+    M = 24576
+    X, noise, r = _inputs(M)
+    for steps in (1, 3):
+        ref = _setup(_lib.F64)
+        z_meas = ref.raycast(np.array([3.0, 4.5, 0.0]), want_hits=False)[0][0]
+        ref.set_particles(X)
+        for _ in range(steps):
+            ref.sample(1.5, 0.0, 0.1, ALPHA, z_meas, noise, seed=99)
+            ref.normalise(_lib.W_LOG)
+            idx = ref.resample(r, _lib.RESAMPLE_PARALLEL)
+        Xr, wr, _ = ref.get_particles()
+        res = run_ranks(_rccl_rank_fn, 1, M, z_meas, True, 256, True, steps, backend="nccl")[0]
+        assert res["fallbacks"] == 0
+        assert np.array_equal(res["idx"], idx)
+        assert np.array_equal(res["X"], Xr) and np.array_equal(res["w"], wr)
 
 
 @pytest.mark.parametrize("device_path", [False, True])
