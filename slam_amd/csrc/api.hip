@@ -135,12 +135,18 @@ int build_ring_table(mclhip_ctx* c) {
   c->ETW = c->TW + 2 * rtx; c->ETH = c->TH + 2 * rty;
   const size_t ne = ((size_t)c->ETW << kQueryShift) * ((size_t)c->ETH << kQueryShift);   // query tiles
   uint32_t* d_cnt = nullptr;
+  uint32_t* d_cls = nullptr;     // cells per class of every list (between the counting and the filling pass)
   MCL_HIP(c, hipMalloc((void**)&d_cnt, ne * sizeof(uint32_t)));
-  int rc = launch_nbr_count(c, d_cnt);
+  if (hipMalloc((void**)&d_cls, ne * kNeedClasses * sizeof(uint32_t)) != hipSuccess) {
+    (void)hipFree(d_cnt);
+    return fail(c, MCLHIP_E_HIP, "neighbourhood count: out of device memory");
+  }
+  int rc = launch_nbr_count(c, d_cnt, d_cls);
   std::vector<uint32_t> cnt(ne);
   hipError_t e = hipStreamSynchronize(c->stream);
   if (e == hipSuccess) e = hipMemcpy(cnt.data(), d_cnt, ne * sizeof(uint32_t), hipMemcpyDeviceToHost);
   (void)hipFree(d_cnt);
+  struct FreeCls { uint32_t* p; ~FreeCls() { if (p) (void)hipFree(p); } } free_cls{d_cls};
   if (rc != MCLHIP_OK) return rc;
   if (e != hipSuccess) return fail(c, MCLHIP_E_HIP, std::string("neighbourhood count: ") + hipGetErrorString(e));
   std::vector<uint64_t> off(ne + 1);
@@ -149,11 +155,12 @@ int build_ring_table(mclhip_ctx* c) {
   off[ne] = acc;
   if (c->nbr_off) { (void)hipFree(c->nbr_off); c->nbr_off = nullptr; }
   if (c->nbr_cells) { (void)hipFree(c->nbr_cells); c->nbr_cells = nullptr; }
+  if (c->nbr_need) { (void)hipFree(c->nbr_need); c->nbr_need = nullptr; }
   // The lists are what the map costs in device memory: four bytes per entry, offsets of eight per query tile.  They
   // are refused, before anything is allocated, when they would not fit what the device has free (less a tenth: the
   // particles come later) -- or MCLHIP_LIST_BUDGET_GB, if the environment sets one.
   {
-    const double need = (double)acc * sizeof(uint32_t) + (double)(ne + 1) * sizeof(uint64_t);
+    const double need = (double)acc * sizeof(uint32_t) + (double)(ne + 1) * sizeof(uint64_t) + (double)ne * sizeof(QueryTile);
     size_t free_b = 0, total_b = 0;
     double budget = 0.0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = 0.9 * (double)free_b;
@@ -166,12 +173,13 @@ int build_ring_table(mclhip_ctx* c) {
     }
   }
   MCL_HIP(c, hipMalloc((void**)&c->nbr_off, (ne + 1) * sizeof(uint64_t)));
+  MCL_HIP(c, hipMalloc((void**)&c->nbr_need, ne * sizeof(QueryTile)));
   // (kListReadAhead entries behind the last list: a kernel that asks for a list's batches ahead of knowing where it ends
   // may read that far beyond it)
   MCL_HIP(c, hipMalloc((void**)&c->nbr_cells, (size_t)(acc + kListReadAhead) * sizeof(uint32_t)));
   MCL_HIP(c, hipMemsetAsync(c->nbr_cells + acc, 0, kListReadAhead * sizeof(uint32_t), c->stream));
   MCL_HIP(c, hipMemcpy(c->nbr_off, off.data(), (ne + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
-  rc = launch_nbr_fill(c);
+  rc = launch_nbr_fill(c, d_cls);
   if (rc != MCLHIP_OK) return rc;
   MCL_HIP(c, hipStreamSynchronize(c->stream));
   c->ring_dirty = false;
@@ -285,6 +293,10 @@ void make_query_prep(const mclhip_ctx* c, QueryPrep& qp) {
   qp.inv_res_xf = (float)(1.0 / c->res_x); qp.inv_res_yf = (float)(1.0 / c->res_y);
   qp.th_mid = (float)c->iv_th_mid; qp.th_hi = (float)c->iv_th_hi;
   qp.origin = (float)c->iv_origin;
+  qp.nbr_need = c->nbr_need;
+  qp.res_xf = (float)c->res_x; qp.res_yf = (float)c->res_y;
+  qp.need_slack = (float)(0.5 * nbr_class_slack(c));   // (half of what the classes' first radius adds to z_max: the other half is the cells')
+  qp.need_inv_step = (float)(1.0 / nbr_class_step(c));
   qp.serve_all = ray_serves_every_heading(c) ? 1 : 0;
 }
 
@@ -398,7 +410,7 @@ void mclhip_destroy(mclhip_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   fs_release(c);
-  void* ptrs[] = {c->obst, c->freeb, c->tile_off, c->cells, c->nbr_off, c->nbr_cells, c->tab_sorted, c->tab_orig, c->perm, c->inv_perm, c->lut, c->relx, c->iv_edge, c->iv_beam, c->iv_lut, c->iv_ends, c->redo_list, c->redo_list2, c->redo_count, c->qrec, c->zt, c->etalam, c->zmeas_stage, c->ring,
+  void* ptrs[] = {c->obst, c->freeb, c->tile_off, c->cells, c->nbr_off, c->nbr_need, c->nbr_cells, c->tab_sorted, c->tab_orig, c->perm, c->inv_perm, c->lut, c->relx, c->iv_edge, c->iv_beam, c->iv_lut, c->iv_ends, c->redo_list, c->redo_list2, c->redo_count, c->qrec, c->zt, c->etalam, c->zmeas_stage, c->ring,
                   c->px[0], c->px[1], c->py[0], c->py[1], c->pth[0], c->pth[1], c->w[0], c->w[1], c->logw, c->pm,
                   c->sx, c->sy, c->sth, c->sw, c->chunk_sums, c->scal, c->cdf_approx, c->cdf_exact, c->kscan,
                   c->fscan, c->blk_a, c->blk_b, c->irr, c->bases, c->idx, c->noise, c->counters, c->range_noise, c->inj_rows, c->stamps,

@@ -56,7 +56,21 @@ int launch_build_tiles(mclhip_ctx* c, const uint8_t* d_map) {
 struct NbrGeom {
   int TW, TH, n_ring, rtx, rty, ETW, ETH;   // obstacle tiles, ring, extended 8x8 tile grid
   double res_x, res_y, reach2, cell_reach2;
+  double class_r0, class_step;              // see cell_class
 };
+
+// A list is kept in kNeedClasses classes by the cells' distance from the CENTRE of the query tile: class 0 within
+// class_r0 (z_max and a little), class j within class_r0 + j * class_step, the last class everything else.  A pose at
+// distance rho from that centre can only reach cells within z_max + rho of it (triangle inequality), so it needs the
+// classes up to ceil(rho / class_step) and no more: the prefix of the list that holds them.  (Poses near the middle of
+// their tile skip the rim that the tile's corners need: 14 % of the batches on the benchmark's map.)
+__device__ inline int cell_class(const NbrGeom& g, int qrow0, int qcol0, uint32_t e) {
+  const double dx = ((double)(int)(e & 0xffffu) - ((double)qcol0 + 0.5 * kQueryCells)) * g.res_x;
+  const double dy = ((double)(int)(e >> 16) - ((double)qrow0 + 0.5 * kQueryCells)) * g.res_y;
+  const double over = sqrt(dx * dx + dy * dy) - g.class_r0;
+  const int k = over <= 0.0 ? 0 : (int)ceil(over / g.class_step);
+  return k > kNeedClasses - 1 ? kNeedClasses - 1 : k;
+}
 
 // fewest whole cells between the query rows / columns [q0, q0 + kQueryCells) and the obstacle tile's [8 o, 8 o + 8)
 __device__ inline int cell_gap(int q0, int o) {
@@ -80,13 +94,15 @@ __device__ inline bool cell_in_reach(const NbrGeom& g, int qrow0, int qcol0, uin
   return gx * gx + gy * gy <= g.cell_reach2;
 }
 
-// One wavefront per query tile.  FILL == false: the length of its list into cnt; true: the list itself, from
-// nbr_off on.
+// One wavefront per query tile.  FILL == false: the length of its list into cnt, the number of cells of every class
+// into cls_cnt; true: the list itself, from nbr_off on, class by class, and how many batches of 64 hold the classes
+// up to k into need[k].
 template <bool FILL>
 __global__ __launch_bounds__(256) void nbr_list_kernel(const uint32_t* __restrict__ tile_off,
                                                        const uint32_t* __restrict__ cells, const uint16_t* __restrict__ ring,
                                                        NbrGeom g, const uint64_t* __restrict__ nbr_off,
-                                                       uint32_t* __restrict__ out_buf) {
+                                                       uint32_t* __restrict__ out_buf, uint32_t* __restrict__ cls_cnt,
+                                                       QueryTile* __restrict__ need) {
   const int SW = g.ETW << kQueryShift, SH = g.ETH << kQueryShift;
   const int lane = threadIdx.x & 63;
   const int64_t t = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -96,6 +112,19 @@ __global__ __launch_bounds__(256) void nbr_list_kernel(const uint32_t* __restric
   const int qrow0 = ty * 8 + (sy & ((1 << kQueryShift) - 1)) * kQueryCells;
   const int qcol0 = tx * 8 + (sx & ((1 << kQueryShift) - 1)) * kQueryCells;
   uint64_t out = FILL ? nbr_off[t] : 0ull;   // (FILL: place in the lists; else: the count, which fits 32 bits)
+  uint32_t at[kNeedClasses];                  // wave-uniform.  FILL: where the next cell of class k goes; else: their number
+#pragma unroll
+  for (int k = 0; k < kNeedClasses; ++k) at[k] = 0u;
+  if (FILL) {
+    uint32_t run = 0u;
+#pragma unroll
+    for (int k = 0; k < kNeedClasses; ++k) {
+      const uint32_t nk = cls_cnt[(size_t)t * kNeedClasses + k];
+      at[k] = run;
+      run += nk;
+      if (lane == 0) { const uint32_t b = (run + 63u) / 64u; need[t].need[k] = (uint16_t)(b > 65535u ? 65535u : b); }
+    }
+  }
   for (int r = 0; r < g.n_ring; ++r) {
     const int y = ty + (int)(ring[r] >> 8) - 128, x = tx + (int)(ring[r] & 0xffu) - 128;
     if (y < 0 || y >= g.TH || x < 0 || x >= g.TW) continue;
@@ -106,14 +135,28 @@ __global__ __launch_bounds__(256) void nbr_list_kernel(const uint32_t* __restric
     const uint32_t e = (uint32_t)lane < n ? cells[o + lane] : 0u;
     const bool keep = (uint32_t)lane < n && cell_in_reach(g, qrow0, qcol0, e);
     const unsigned long long km = __ballot(keep);
-    if (FILL && keep) {
-      const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
-      out_buf[out + pos] = e;
+    if (km == 0ull) continue;
+    const int cls = keep ? cell_class(g, qrow0, qcol0, e) : -1;
+#pragma unroll
+    for (int k = 0; k < kNeedClasses; ++k) {
+      const unsigned long long cm = __ballot(cls == k);
+      if (FILL && cls == k) {
+        const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
+        out_buf[out + at[k] + pos] = e;
+      }
+      at[k] += (uint32_t)__popcll(cm);
     }
-    out += (uint32_t)__popcll(km);
+    if (!FILL) out += (uint32_t)__popcll(km);
   }
-  if (!FILL && lane == 0) out_buf[t] = (uint32_t)out;
+  if (!FILL) {
+    if (lane == 0) out_buf[t] = (uint32_t)out;
+#pragma unroll
+    for (int k = 0; k < kNeedClasses; ++k)
+      if (lane == k) cls_cnt[(size_t)t * kNeedClasses + k] = at[k];
+  }
   if (FILL) {
+    out += at[kNeedClasses - 1];              // (the last class's end: the list's)
+    if (lane == 0) { need[t].first = nbr_off[t]; need[t].n_cells = (uint32_t)(nbr_off[t + 1] - nbr_off[t]); need[t].pad = 0u; }
     // A list occupies whole batches of 64 entries; the rest of the last batch is a cell no pose of the query tile can
     // reach (the far end of the column range: reach is at most 127 tiles), so that a walk needs no per-lane bounds.
     const uint32_t pad = qcol0 < 32768 ? 0xffffu : 0u;   // row 0, last or first column
@@ -129,21 +172,23 @@ static NbrGeom nbr_geom(const mclhip_ctx* c) {
   g.reach2 = reach * reach;
   const double cell_reach = c->z_max + (c->res_x + c->res_y);
   g.cell_reach2 = cell_reach * cell_reach;
+  g.class_r0 = c->z_max + nbr_class_slack(c);
+  g.class_step = nbr_class_step(c);
   return g;
 }
 
-int launch_nbr_count(mclhip_ctx* c, uint32_t* d_cnt) {
+int launch_nbr_count(mclhip_ctx* c, uint32_t* d_cnt, uint32_t* d_cls_cnt) {
   const int64_t ne = ((int64_t)c->ETW << kQueryShift) * ((int64_t)c->ETH << kQueryShift);
   hipLaunchKernelGGL(nbr_list_kernel<false>, dim3((unsigned)((ne + 3) / 4)), dim3(256), 0, c->stream, c->tile_off, c->cells,
-                     c->ring, nbr_geom(c), (const uint64_t*)nullptr, d_cnt);
+                     c->ring, nbr_geom(c), (const uint64_t*)nullptr, d_cnt, d_cls_cnt, (QueryTile*)nullptr);
   MCL_HIP(c, hipGetLastError());
   return MCLHIP_OK;
 }
 
-int launch_nbr_fill(mclhip_ctx* c) {
+int launch_nbr_fill(mclhip_ctx* c, uint32_t* d_cls_cnt) {
   const int64_t ne = ((int64_t)c->ETW << kQueryShift) * ((int64_t)c->ETH << kQueryShift);
   hipLaunchKernelGGL(nbr_list_kernel<true>, dim3((unsigned)((ne + 3) / 4)), dim3(256), 0, c->stream, c->tile_off, c->cells,
-                     c->ring, nbr_geom(c), c->nbr_off, c->nbr_cells);
+                     c->ring, nbr_geom(c), c->nbr_off, c->nbr_cells, d_cls_cnt, c->nbr_need);
   MCL_HIP(c, hipGetLastError());
   return MCLHIP_OK;
 }
@@ -265,9 +310,21 @@ __global__ __launch_bounds__(256) void motion_kernel(T* __restrict__ xs, T* __re
     if (pose_ok && served) {
       const int ex = (((int)floorf(fxc)) >> (3 - kQueryShift)) + q.rtx, ey = (((int)floorf(fyc)) >> (3 - kQueryShift)) + q.rty;
       if (ex >= 0 && ex < q.ETW && ey >= 0 && ey < q.ETH) {
-        const uint64_t* no = q.nbr_off + ((size_t)ey * q.ETW + ex);
-        first = no[0];
-        n_cells = (uint32_t)(no[1] - first);
+        const size_t tile = (size_t)ey * q.ETW + ex;
+        const uint4* src_ = reinterpret_cast<const uint4*>(q.nbr_need + tile);     // (one 32-byte read)
+        const uint4 t0 = src_[0], t1 = src_[1];
+        first = (uint64_t)t0.x | ((uint64_t)t0.y << 32);
+        n_cells = t0.z;
+        // of the list only the classes this pose can reach (see cell_class): by its distance from the centre of the tile
+        // it was filed under
+        const float cx = (float)(((ex - q.rtx) * kQueryCells) + kQueryCells / 2), cy = (float)(((ey - q.rty) * kQueryCells) + kQueryCells / 2);
+        const float dxm = (fxc - cx) * q.res_xf, dym = (fyc - cy) * q.res_yf;
+        const float rho = sqrtf(dxm * dxm + dym * dym);
+        int k = (int)ceilf((rho + q.need_slack) * q.need_inv_step);
+        k = k < 0 ? 0 : (k > kNeedClasses - 1 ? kNeedClasses - 1 : k);
+        const uint64_t half = k < 4 ? ((uint64_t)t1.x | ((uint64_t)t1.y << 32)) : ((uint64_t)t1.z | ((uint64_t)t1.w << 32));
+        const uint32_t part = 64u * (uint32_t)((half >> (16 * (k & 3))) & 0xffffull);
+        n_cells = part < n_cells ? part : n_cells;
       }
     }
     rec.first_lo = (uint32_t)first; rec.first_hi = (uint32_t)(first >> 32); rec.n_cells = n_cells;

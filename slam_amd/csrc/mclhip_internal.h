@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cmath>
 #include <string>
 #include <vector>
 
@@ -30,6 +31,7 @@ constexpr int kScanTile = kScanBlock * kScanItems;
 #endif
 constexpr int kQueryShift = MCL_QUERY_SHIFT;        // 0: 8x8 cells, 1: 4x4, 2: 2x2
 constexpr int kQueryCells = 8 >> kQueryShift;
+constexpr int kNeedClasses = 8;   // a query tile's list is kept in this many classes by distance from the tile's centre (map_motion.hip: cell_class)
 
 // Everything the sector-query kernel needs about the map and the sensor.
 struct RayParams {
@@ -128,6 +130,14 @@ struct QueryRecord {
                          // angles two or more turns away.  The slice is filled in for either.
 };
 static_assert(sizeof(QueryRecord) == 32, "two 16-byte loads");
+// What the motion kernel reads of a query tile, in one 32-byte load: where the tile's list starts, how long it is, and
+// how many batches of it hold the classes up to k.
+struct QueryTile {
+  uint64_t first;
+  uint32_t n_cells, pad;
+  uint16_t need[kNeedClasses];
+};
+static_assert(sizeof(QueryTile) == 32, "one 32-byte load");
 struct QueryPrep {
   QueryRecord* out;      // null: no records are written
   const uint64_t* nbr_off;
@@ -135,6 +145,10 @@ struct QueryPrep {
   float inv_res_xf, inv_res_yf;
   float th_mid, th_hi;   // |heading - th_mid| <= th_hi: served by the interval path (RayParams::iv_th_*)
   float origin;          // RayParams::iv_origin
+  // the list's classes (map_motion.hip: cell_class): need[k] = batches of 64 that hold the classes up to k; a pose
+  // at distance rho from its tile's centre takes class ceil((rho + need_slack) * need_inv_step)
+  const QueryTile* nbr_need;
+  float res_xf, res_yf, need_slack, need_inv_step;
   int serve_all;         // every finite heading is served (the interval-only kernel at hand handles the ones outside the range)
 };
 
@@ -169,6 +183,7 @@ struct mclhip_ctx {
   uint32_t* tile_off = nullptr; // per-tile obstacle lists: offsets ...
   uint32_t* cells = nullptr;    // ... and entries
   uint64_t* nbr_off = nullptr;  // per-tile neighbourhood lists (built from the two above and the ring table)
+  mcl::QueryTile* nbr_need = nullptr; // [query tiles] start, length and class prefixes of every list (QueryPrep::nbr_need)
   uint32_t* nbr_cells = nullptr;
   int ETW = 0, ETH = 0, rtx = 0, rty = 0;
   int64_t n_obstacles = 0;
@@ -321,8 +336,8 @@ int set_sensor_table(mclhip_ctx* c, const double* tab_rad, int B, double z_max, 
 int launch_grid_update(mclhip_ctx* c, const double* d_x, const double* d_y, const double* d_th, const int32_t* d_cell,
                        int64_t n, int n_dir, int beams_per_dir, const double* pk_pred, float* pk);
 int build_ring_table(mclhip_ctx* c);
-int launch_nbr_count(mclhip_ctx* c, uint32_t* d_cnt);
-int launch_nbr_fill(mclhip_ctx* c);
+int launch_nbr_count(mclhip_ctx* c, uint32_t* d_cnt, uint32_t* d_cls_cnt);
+int launch_nbr_fill(mclhip_ctx* c, uint32_t* d_cls_cnt);
 int launch_motion(mclhip_ctx* c, void* x, void* y, void* th, uint8_t* pm, int64_t n, const MotionParams& mp,
                   const int16_t* d_noise, int dtype);
 int launch_inject_device(mclhip_ctx* c, int which_buffer, const mcl::MotionParams& mp, double p_random, double ext_x,
@@ -340,6 +355,13 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
                    const QueryRecord* qrec = nullptr);
 // fills mp.qp so that the motion kernel leaves the records of the sector query that follows (or out = null: none)
 void make_query_prep(const mclhip_ctx* c, QueryPrep& qp);
+// the classes of a neighbourhood list (map_motion.hip: cell_class): a little beyond z_max for what rounding can move a
+// cell or a pose; the step is a seventh of the farthest a pose can stand from its query tile's centre
+inline double nbr_class_slack(const mclhip_ctx* c) { return 0.02 * (c->res_x < c->res_y ? c->res_x : c->res_y); }
+inline double nbr_class_step(const mclhip_ctx* c) {
+  const double hx = 0.5 * kQueryCells * c->res_x, hy = 0.5 * kQueryCells * c->res_y;
+  return std::sqrt(hx * hx + hy * hy) / (kNeedClasses - 1);
+}
 // > 0: the beam table at hand is one of the interval-only kernel's arithmetic layouts (that many intervals per sector)
 int ray_arith_span(const mclhip_ctx* c);
 // ... and that kernel also serves the headings outside the circular range

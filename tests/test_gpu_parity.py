@@ -673,6 +673,12 @@ def test_one_kernel_and_two_launch_sector_query_agree_bit_for_bit(monkeypatch):
     th = rng.uniform(-6.5, 6.5, M)                       # a sixth outside the range (|heading| > 355 degrees and beyond)
     th[:500] = np.round(rng.uniform(0, 72, 500)) * (5 * np.pi / 180.0)   # lattice headings: cells exactly on sector edges
     X[:, 2] = th
+    # poses on and next to the corners, edges and centres of the 8 x 8-cell tiles the cell lists are kept for: the
+    # two-launch path reads only the part of a tile's list that a pose at that distance from the tile's centre can
+    # reach (the one-kernel path reads all of it)
+    k = np.arange(2000)
+    X[1000:3000, 0] = (8 * rng.randint(2, 30, 2000) + np.array([0.0, 4.0, 8.0, 7.999])[k % 4]) * W.RES + rng.choice([0.0, 1e-6, -1e-6], 2000)
+    X[1000:3000, 1] = (8 * rng.randint(2, 30, 2000) + np.array([0.0, 4.0, 8.0, 7.999])[(k // 4) % 4]) * W.RES + rng.choice([0.0, 1e-6, -1e-6], 2000)
     X = X.astype(np.float32).astype(np.float64)
     w4 = np.array([0.97, 0.005, 0.020, 0.005]); w4 /= w4.sum()
     zero = np.zeros((M, 3, 12), np.int16)
