@@ -23,11 +23,13 @@ constexpr int kScanTile = kScanBlock * kScanItems;
 
 // Neighbourhood lists are kept per QUERY tile of (8 >> kQueryShift)^2 cells: the smaller the query tile, the
 // fewer cells of its list lie outside a particle's disk (and the more lists there are).  With every cell of a list
-// tested against the query tile (reach z_max plus a cell), an 8x8 query tile on a map with 4 % of its cells
-// occupied lists about 204 cells for the 132 within z_max of a pose; 4x4 query tiles would list about 180 at three
-// and a half times the list memory -- hence 8x8.
+// tested against the query tile (reach z_max plus a cell) and a pose walking only the classes of the list it can
+// reach (kNeedClasses), an 8x8 query tile on a map with 4 % of its cells occupied has a pose walk 3.08 batches of 64
+// for the 132 cells within z_max, a 4x4 query tile fewer: measured on one GPU, 2^20 x 180, the interval-only launch
+// 0.577 -> 0.562 ms (global regime) and 0.543 -> 0.529 ms (tracking) at three and a half times the list memory (0.7 GB
+// for a 4096^2 map, 14 GB for 16384^2) -- memory this part has to spare; hence 4x4.
 #ifndef MCL_QUERY_SHIFT
-#define MCL_QUERY_SHIFT 0
+#define MCL_QUERY_SHIFT 1
 #endif
 constexpr int kQueryShift = MCL_QUERY_SHIFT;        // 0: 8x8 cells, 1: 4x4, 2: 2x2
 constexpr int kQueryCells = 8 >> kQueryShift;
