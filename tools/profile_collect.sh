@@ -35,7 +35,7 @@ if [ -d $src/grid ]; then
   cp $src/grid_trace/t_kernel_stats.csv profiles/${tag}_grid_kernel_stats.csv
   python tools/pmc_summary.py $src/grid profiles/${tag}_grid_pmc_per_kernel.json > /dev/null
   python tools/valu_roofline.py profiles/${tag}_grid_pmc_per_kernel.json profiles/r02_valu_issue_cost.json /tmp/raycast_$tag.s \
-      raycast_kernelIdLb0ELb0ELb1ELi12ELb0ELb0ELb0ELb0ELi0ELin1E profiles/${tag}_grid_valu_roofline.json "raycast_kernel<double, false, false, true, 12" \
+      raycast_kernelIdLb0ELb0ELb1ELi16ELb0ELb0ELb0ELb0ELi0ELin1E profiles/${tag}_grid_valu_roofline.json "raycast_kernel<double, false, false, true, 16" \
       --sources $RAYSRC
 fi
 if [ -d $src/fastslam ]; then
