@@ -279,6 +279,7 @@ static MotionParams make_motion_params(const mclhip_ctx* c, double v, double ome
   mp.seed = seed;
   mp.index0 = c->first_index;
   mp.qp.out = nullptr;
+  mp.prep.zt = nullptr;
   return mp;
 }
 
@@ -322,12 +323,16 @@ static int enqueue_sample(mclhip_ctx* c, double v, double omega, double dt, cons
   // log-weights from the float32 mixture: the query may run as the interval-only kernel, which reads the motion
   // kernel's records (launch_raycast decides; records it does not use cost 32 bytes per particle of writes)
   if (!want_product && !d_range_noise && !(rn_sigma > 0.0) && c->zmeas_ok) make_query_prep(c, mp.qp);
+  // (the measurement's table and the left-over counts are the query's business: one more block of the motion kernel
+  // sees to both, see StepPrep)
+  mp.prep.zt = c->zt; mp.prep.etalam = c->etalam; mp.prep.zmeas = c->zmeas_stage; mp.prep.perm = c->perm;
+  mp.prep.B = c->B; mp.prep.lambda = c->lambda;
+  mp.prep.clear = c->redo_count; mp.prep.n_clear = c->redo_count ? 2 * 64 : 0;
   span_begin(c, spans, 1);
   MCL_TRY(launch_motion(c, c->px[a], c->py[a], c->pth[a], c->pm, c->M, mp, c->noise, c->dtype));
   span_end(c, spans);
-  // (the measurement's table is the query's business: behind the motion kernel, so that a caller that has just waited
-  // for the GPU gets it started one launch sooner)
-  MCL_TRY(launch_beam_table(c));
+  if (c->M <= 0) MCL_TRY(launch_beam_table(c));   // (no launch, no extra block)
+  else c->redo_cleared = c->redo_count != nullptr;
   // (timed inside: group 0 around its kernel, or around the first of its two kernels and group 5 around the second)
   // the raw product is only formed when somebody will read it: it costs one dependent multiply per beam
   MCL_TRY(launch_raycast(c, c->px[a], c->py[a], c->pth[a], c->pm, c->M, c->dtype, want_product ? c->w[a] : nullptr,

@@ -249,7 +249,24 @@ template <typename T>
 __global__ __launch_bounds__(256) void motion_kernel(T* __restrict__ xs, T* __restrict__ ys, T* __restrict__ ths,
                                                      uint8_t* __restrict__ pm, int64_t n, MotionParams mp,
                                                      const int16_t* __restrict__ noise) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t blk = blockIdx.x;
+  if (mp.prep.zt) {
+    // block 0: the measurement's per-beam constants, as beam_table_kernel forms them, and the counts the sector query
+    // adds to (see StepPrep)
+    if (blk == 0) {
+      const StepPrep& sp = mp.prep;
+      for (int k = threadIdx.x; k < sp.B; k += blockDim.x) {
+        const double z = sp.zmeas[sp.perm[k]];
+        const double eta = 1.0 / (1.0 - exp(-sp.lambda * z));
+        sp.zt[k] = z;
+        sp.etalam[k] = eta * sp.lambda;
+      }
+      if (sp.clear && (int)threadIdx.x < sp.n_clear) sp.clear[threadIdx.x] = 0u;
+      return;
+    }
+    blk -= 1;
+  }
+  int64_t i = blk * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double x = (double)xs[i], y = (double)ys[i], th = (double)ths[i];
   double v_hat = mp.v, w_hat = mp.omega, g_hat = 0.0;
@@ -478,7 +495,7 @@ int launch_restore(mclhip_ctx* c, void* x, void* y, void* th, double* w, const v
 int launch_motion(mclhip_ctx* c, void* x, void* y, void* th, uint8_t* pm, int64_t n, const MotionParams& mp,
                   const int16_t* d_noise, int dtype) {
   if (n <= 0) return MCLHIP_OK;
-  dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  dim3 grid((unsigned)((n + 255) / 256 + (mp.prep.zt ? 1 : 0))), block(256);
   if (dtype == MCLHIP_F32)
     hipLaunchKernelGGL(motion_kernel<float>, grid, block, 0, c->stream, (float*)x, (float*)y, (float*)th, pm, n, mp,
                        d_noise);

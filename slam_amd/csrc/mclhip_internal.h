@@ -154,6 +154,19 @@ struct QueryPrep {
   int serve_all;         // every finite heading is served (the interval-only kernel at hand handles the ones outside the range)
 };
 
+// What the sector query that follows a motion launch needs beside the poses: the measurement's per-beam constants
+// (map_motion.hip: beam_table_kernel) and the left-over lists' counts at zero.  One more block of the motion kernel
+// does both, instead of a kernel and a fill of their own between the two big launches.
+struct StepPrep {
+  double* zt;            // null: nothing to prepare
+  double* etalam;
+  const double* zmeas;
+  const uint16_t* perm;
+  uint32_t* clear;       // [n_clear] words set to zero (n_clear <= 256), or null
+  int B, n_clear;
+  double lambda;
+};
+
 struct MotionParams {
   double v, omega, dt;
   double c1, c2, c3;     // b/6 for the three draws
@@ -166,6 +179,7 @@ struct MotionParams {
   uint64_t seed;
   int64_t index0;        // global index of particle 0 (keys the device generator)
   QueryPrep qp;          // records for the sector query that follows (float32 state, sector intervals), or out == null
+  StepPrep prep;         // the query's per-step tables, prepared by one extra block (zt == null: not)
 };
 
 }  // namespace mcl
@@ -223,6 +237,7 @@ struct mclhip_ctx {
   int64_t M = 0, cap = 0;
   int32_t* redo_list2 = nullptr;   // ... and what the second pass over that list left over in turn (its counts: redo_count + 64)
   int32_t* redo_list = nullptr; uint32_t* redo_count = nullptr; int64_t redo_cap = 0;   // particles the interval-only sector query left over
+  bool redo_cleared = false;       // the motion launch just enqueued has set redo_count[] to zero (launch_raycast then need not)
   mcl::QueryRecord* qrec = nullptr;   // [cap] the motion kernel's records for the interval-only sector query
   static constexpr int64_t kRedoSlack = 64 * 16 * 2;   // the 64 lists are rounded up to whole blocks of waves
   // How many particles the interval-only launch left over last time (page-locked host copy of the 64 counters, written

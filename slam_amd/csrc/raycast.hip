@@ -1485,6 +1485,9 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
                    int dtype, double* w_out, double* logw_out, double* ranges_out, int32_t* hits_out,
                    const double* range_noise, double rn_sigma, uint64_t rn_seed, const QueryRecord* qrec) {
   const bool product = w_out != nullptr;
+  // (whether the motion launch before this one has cleared the left-over counts: said once, for the launch that follows it)
+  const bool counts_cleared = c->redo_cleared;
+  c->redo_cleared = false;
   if (n <= 0) return MCLHIP_OK;
   RayParams P = make_ray_params(c);
   P.range_noise = range_noise;
@@ -1569,7 +1572,7 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
       if ((int64_t)P.sub_cap * kSubLists > c->redo_cap + mclhip_ctx::kRedoSlack) return fail(c, MCLHIP_E_LIMIT, "left-over list too small");
       const size_t lds_b = ray_lds_bytes(P.B, P.G, P.NB, false, kWavesPerBlock, 0, 0, 0, 0, 0);   // the second launch's
       if (lds_b > 160 * 1024) return fail(c, MCLHIP_E_LIMIT, "beam table does not fit the kernel's LDS budget");
-      MCL_HIP(c, hipMemsetAsync(c->redo_count, 0, 2 * kSubLists * sizeof(uint32_t), c->stream));   // (both lists' counts)
+      if (!counts_cleared) MCL_HIP(c, hipMemsetAsync(c->redo_count, 0, 2 * kSubLists * sizeof(uint32_t), c->stream));   // (both lists' counts)
       P.redo_list = c->redo_list; P.redo_count = c->redo_count;
       timing_begin(c, 0);
       const bool even = c->iv_uniform;                                       // equally wide intervals
