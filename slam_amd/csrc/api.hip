@@ -96,6 +96,7 @@ RayParams make_ray_params(const mclhip_ctx* c) {
   P.w_hit = c->w4[0]; P.w_short = c->w4[1]; P.w_max = c->w4[2]; P.w_rand = c->w4[3];
   P.p_rand = 1 / c->z_max;                               // range_sensor.py:64
   P.redo_list = nullptr; P.redo_count = nullptr; P.list = nullptr; P.list_count = nullptr; P.sub_cap = 0;
+  P.hint_out = nullptr; P.hint_src = nullptr;
   P.range_noise = nullptr;
   P.rn_sigma = 0.0; P.rn_seed = 0; P.rn_index0 = c->first_index;
   P.stamps = c->stamps;
@@ -325,7 +326,10 @@ static int enqueue_sample(mclhip_ctx* c, double v, double omega, double dt, cons
   if (!want_product && !d_range_noise && !(rn_sigma > 0.0) && c->zmeas_ok) make_query_prep(c, mp.qp);
   // (the measurement's table and the left-over counts are the query's business: one more block of the motion kernel
   // sees to both, see StepPrep)
-  mp.prep.zt = c->zt; mp.prep.etalam = c->etalam; mp.prep.zmeas = c->zmeas_stage; mp.prep.perm = c->perm;
+  if (!c->zsrc || c->zsrc_slot < 0) return fail(c, MCLHIP_E_STATE, "no measurement at hand");
+  const int zk = c->zsrc_slot;
+  if (c->M <= 0) MCL_HIP(c, hipMemcpyAsync(c->zmeas_stage, c->zsrc, c->B * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  mp.prep.zt = c->zt; mp.prep.etalam = c->etalam; mp.prep.zmeas = c->zsrc; mp.prep.perm = c->perm;
   mp.prep.B = c->B; mp.prep.lambda = c->lambda;
   mp.prep.clear = c->redo_count; mp.prep.n_clear = c->redo_count ? 2 * 64 : 0;
   span_begin(c, spans, 1);
@@ -333,6 +337,8 @@ static int enqueue_sample(mclhip_ctx* c, double v, double omega, double dt, cons
   span_end(c, spans);
   if (c->M <= 0) MCL_TRY(launch_beam_table(c));   // (no launch, no extra block)
   else c->redo_cleared = c->redo_count != nullptr;
+  MCL_HIP(c, hipEventRecord(c->zev[zk], c->stream));   // the measurement's slot has been read once this has passed
+  c->zev_set[zk] = true;
   // (timed inside: group 0 around its kernel, or around the first of its two kernels and group 5 around the second)
   // the raw product is only formed when somebody will read it: it costs one dependent multiply per beam
   MCL_TRY(launch_raycast(c, c->px[a], c->py[a], c->pth[a], c->pm, c->M, c->dtype, want_product ? c->w[a] : nullptr,
@@ -351,9 +357,9 @@ static int upload_zmeas(mclhip_ctx* c, const double* z_meas) {
   bool ok = true;
   for (int b = 0; b < c->B; ++b) ok = ok && (z_meas[b] >= 0.0) && (z_meas[b] <= 1.0e9);   // false for NaN as well
   c->zmeas_ok = ok;
-  MCL_HIP(c, hipMemcpyAsync(c->zmeas_stage, host, c->B * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  MCL_HIP(c, hipEventRecord(c->zev[k], c->stream));
-  c->zev_set[k] = true;
+  // (no copy: the sample step that follows reads the slot in place -- one block of its motion launch -- and marks the
+  // slot as read, see enqueue_sample)
+  c->zsrc = host; c->zsrc_slot = k;
   return MCLHIP_OK;
 }
 
@@ -555,6 +561,7 @@ int mcl::set_sensor_table(mclhip_ctx* c, const double* tab_rad, int B, double z_
   for (int k = 0; k < mclhip_ctx::kZSlots; ++k)
     if (c->zev_set[k]) { MCL_HIP(c, hipEventSynchronize(c->zev[k])); c->zev_set[k] = false; }
   if (c->zpin) { (void)hipHostFree(c->zpin); c->zpin = nullptr; }
+  c->zsrc = nullptr; c->zsrc_slot = -1;
   MCL_HIP(c, hipHostMalloc((void**)&c->zpin, (size_t)mclhip_ctx::kZSlots * B * sizeof(double), hipHostMallocDefault));
   MCL_HIP(c, hipMemcpy(c->tab_sorted, ts.data(), B * sizeof(double), hipMemcpyHostToDevice));
   MCL_HIP(c, hipMemcpy(c->tab_orig, tab.data(), B * sizeof(double), hipMemcpyHostToDevice));

@@ -110,6 +110,10 @@ struct RayParams {
   const uint16_t* g_member;    // [NE] entries by class
   const double* g_ar;          // [B0] beam angles in radians, [D] heading angles: an entry's own angle is their sum (robot.py:252)
   const double* g_thd;
+  // the launch over the left-over list: block 0 stores the lists' counts (64 + 64) where the host reads them as a hint
+  // for the next query (page-locked host memory; no copy of their own)
+  uint32_t* hint_out;
+  const uint32_t* hint_src;
 };
 
 // What the interval-only sector query needs of a particle, left by the motion kernel in one 32-byte record: the
@@ -225,6 +229,8 @@ struct mclhip_ctx {
   // caller's buffer after the call has returned.  kZSlots steps may be in flight before a slot is waited for.
   static constexpr int kZSlots = 8;
   double* zpin = nullptr;         // [kZSlots][B], host
+  const double* zsrc = nullptr;   // the measurement the next sample step reads: a slot of zpin (the step's motion launch reads it in place)
+  int zsrc_slot = -1;
   hipEvent_t zev[kZSlots] = {};   // upload of the slot has finished
   bool zev_set[kZSlots] = {};
   int zslot = 0;

@@ -271,6 +271,11 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
   extern __shared__ __align__(16) unsigned char smem[];
   // LISTED: the launch is sized for every particle, the list is usually short: a block beyond it leaves at once
   if constexpr (LISTED) {
+    // (the entry-by-entry launch, the last of a query: the lists' counts go where the host reads them, see hint_out --
+    // before block 0 finds out whether it has anything else to do)
+    if constexpr (FAST && !IVONLY) {
+      if (blockIdx.x == 0 && P.hint_out != nullptr && threadIdx.x < 2 * kSubLists) P.hint_out[threadIdx.x] = P.hint_src[threadIdx.x];
+    }
     if ((int64_t)(blockIdx.x / kSubLists) * WPB >= (int64_t)P.list_count[blockIdx.x % kSubLists]) return;
   }
   const int B = P.B, NB = P.NB;
@@ -1618,6 +1623,7 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
       P.redo_list = nullptr; P.redo_count = nullptr;
       P.list = every ? c->redo_list2 : c->redo_list; P.list_count = every ? c->redo_count + kSubLists : c->redo_count;
       P.iv_NE = 0; P.iv_cmax = 0;
+      P.hint_out = c->redo_hint; P.hint_src = c->redo_count;    // (both lists' counts are final by now)
       int64_t blocks_b = (n + kWavesPerBlock - 1) / kWavesPerBlock;
       // (two rounds of the blocks a chip holds: measured at 2^20 particles with 33000 left over, 16384 blocks 0.070 ms,
       // 7168 0.067, 3584 0.063, 1792 0.062, 896 0.083)
@@ -1633,8 +1639,6 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
                            (const QueryRecord*)nullptr);
       }
       timing_end(c);
-      if (c->redo_hint)
-        MCL_HIP(c, hipMemcpyAsync(c->redo_hint, c->redo_count, 2 * kSubLists * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
       c->every_last = every;
     }
     else if (fast && wpb != kWavesPerBlock) MCL_RAY_W(float, false, false, false, true, 2 * kWavesPerBlock, false, false, 0);

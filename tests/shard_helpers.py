@@ -111,7 +111,17 @@ class NumpyShardBackend:
 
 
 def run_ranks(fn, world, *args, backend="gloo"):
-    """fn(rank, world, dist, *args) in `world` fresh processes; returns the per-rank results."""
+    """fn(rank, world, dist, *args) in `world` fresh processes; returns the per-rank results.  A rendezvous port that
+    somebody else took between its choice and the store's listen() (EADDRINUSE) gets one more go with another port."""
+    try:
+        return _run_ranks_once(fn, world, *args, backend=backend)
+    except AssertionError as e:
+        if "EADDRINUSE" not in str(e):
+            raise
+    return _run_ranks_once(fn, world, *args, backend=backend)
+
+
+def _run_ranks_once(fn, world, *args, backend="gloo"):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

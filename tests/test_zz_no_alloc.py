@@ -76,11 +76,21 @@ def test_static_stage_query_matches_the_allocating_one():
 
 
 def _free_device_bytes():
-    """hipMemGetInfo of the current device, asked of the HIP runtime the library itself is linked against."""
-    hip = ctypes.CDLL("libamdhip64.so")
-    free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
-    assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
-    return free.value
+    """hipMemGetInfo of the current device, asked of a HIP runtime this process has already loaded and initialised: the
+    one the library is linked against (under /opt/rocm) first.  A process that has imported torch as well holds torch's
+    own copy of the runtime too, and a bare dlopen("libamdhip64.so") may then come back with an instance that sees no
+    device."""
+    paths = {line.split()[-1] for line in open("/proc/self/maps") if "libamdhip64" in line}
+    assert paths, "no HIP runtime loaded"
+    codes = []
+    for path in sorted(paths, key=lambda q: (not q.startswith("/opt/rocm"), q)):
+        hip = ctypes.CDLL(path)
+        free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        rc = hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total))
+        if rc == 0:
+            return free.value
+        codes.append((path, rc))
+    raise AssertionError("hipMemGetInfo failed: %r" % (codes,))
 
 
 def test_static_stage_query_allocates_no_device_memory():
@@ -94,6 +104,8 @@ def test_static_stage_query_allocates_no_device_memory():
     P = np.stack([rng.uniform(0, 38, 4096), rng.uniform(0, 38, 4096), rng.uniform(-3, 3, 4096)], 1)
     ctx.raycast(P, static=True)                       # first call: whatever the runtime sets up lazily happens here
     ctx.sync()
+    import gc
+    gc.collect()                                      # (contexts of earlier tests give their memory back now, not in between)
     before = _free_device_bytes()
     low = before
     for n in (4096, 1, 300):
