@@ -386,9 +386,14 @@ __global__ void finalize_cdf_kernel(const unsigned long long* __restrict__ ks, c
 }
 
 // index(m) = number of c_i that are < U_m, U_m = r + m/M  (mc_localization.py:254-257)
-// (a two-level search -- a 1024-entry sample of the running sums staged in LDS per block, then the last ten probes in
-// memory -- was measured at 2^20 particles: 26 us against 18.5 us for this plain one; the staging round costs more
-// than the ten L2 probes it saves)
+// A wavefront serves 64 consecutive positions.  U ascends with m and the running sums ascend with i, so the answers of
+// the wave lie between the answer for its first position and the answer for its last.  The wave finds those two
+// together -- half of it probes for each, 32 places at a time: four rounds of dependent reads for a million sums
+// instead of twenty per lane --, stages the sums between them in LDS and every lane finishes there.  A stretch longer
+// than kSearchSpan (many particles of next to no weight between two positions) is cut in 64 by one more round of
+// probes, and every lane searches its piece nine ways at a time.  Same comparisons as a plain binary search, hence
+// the same indices.  (At 2^20 particles that search took 21 us, a chain of twenty dependent reads.)
+constexpr int kSearchSpan = 256;
 template <typename T>
 __global__ __launch_bounds__(256) void search_gather_kernel(const double* __restrict__ cdf, int64_t n, double r,
                                                             const T* __restrict__ x, const T* __restrict__ y,
@@ -396,14 +401,100 @@ __global__ __launch_bounds__(256) void search_gather_kernel(const double* __rest
                                                             T* __restrict__ x2, T* __restrict__ y2,
                                                             T* __restrict__ th2, double* __restrict__ w2,
                                                             int64_t* __restrict__ idx) {
-  int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= n) return;
+  __shared__ double s_c[4][kSearchSpan];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t m0 = (int64_t)blockIdx.x * blockDim.x + (int64_t)wv * 64;
+  if (m0 >= n) return;                                   // (the whole wave)
+  const int64_t m = m0 + lane;
+  const int64_t m_last = m0 + 63 < n ? m0 + 63 : n - 1;
   const double U = r + ((double)m / (double)n);
-  int64_t lo = 0, hi = n;  // first i with !(U > cdf[i])
-  while (lo < hi) {
-    const int64_t mid = (lo + hi) >> 1;
-    if (U > cdf[mid]) lo = mid + 1; else hi = mid;
+  // the two ends: first i with !(u > cdf[i]), n if none -- lanes 0..31 for the first position, 32..63 for the last
+  int64_t L, H;
+  {
+    const int half = lane >> 5, hl = lane & 31;
+    const double u = r + ((double)(half ? m_last : m0) / (double)n);
+    int64_t lo = 0, hi = n;                              // the same in all lanes of a half
+    while (__ballot(hi - lo > 32) != 0ull) {
+      const bool open = hi - lo > 32;
+      const int64_t step = (hi - lo + 31) / 32;
+      const int64_t p = lo + (int64_t)hl * step;
+      const bool in = open && p < hi;
+      const unsigned int hit = (unsigned int)(__ballot(in && !(u > cdf[p])) >> (32 * half));
+      const unsigned int valid = (unsigned int)(__ballot(in) >> (32 * half));
+      if (open) {
+        if (hit == 0u) {
+          lo = lo + (int64_t)(31 - __clz((int)valid)) * step + 1;     // beyond the last place probed
+        } else {
+          const int f = __ffs((int)hit) - 1;
+          hi = lo + (int64_t)f * step;
+          if (f > 0) lo = lo + (int64_t)(f - 1) * step + 1;
+        }
+      }
+    }
+    const int64_t p = lo + hl;
+    const unsigned int hit = (unsigned int)(__ballot(p < hi && !(u > cdf[p])) >> (32 * half));
+    const int64_t ans = hit == 0u ? hi : lo + (__ffs((int)hit) - 1);
+    L = __shfl((long long)ans, 0, 64);
+    H = __shfl((long long)ans, 32, 64);
   }
+  // every lane's answer lies in [L, H]
+  int64_t lo = L, hi = H;
+  if (H - L <= kSearchSpan) {
+    for (int64_t k = lane; k < H - L; k += 64) s_c[wv][k] = cdf[L + k];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    int a = 0, b = (int)(H - L);
+    while (a < b) {
+      const int mid = (a + b) >> 1;
+      if (U > s_c[wv][mid]) a = mid + 1; else b = mid;
+    }
+    lo = L + a;
+  } else {
+    {
+      // 64 places across the stretch, one per lane; every lane then knows the piece between two of them that holds its answer
+      const int64_t step = (H - L + 63) / 64;
+      const int64_t p = L + (int64_t)lane * step;
+      s_c[wv][lane] = p < H ? cdf[p] : INFINITY;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      int a = 0, b = 64;                                 // first j with !(U > s[j])
+      while (a < b) {
+        const int mid = (a + b) >> 1;
+        if (U > s_c[wv][mid]) a = mid + 1; else b = mid;
+      }
+      if (a > 0) lo = L + (int64_t)(a - 1) * step + 1;
+      if (a < 64 && L + (int64_t)a * step < H) hi = L + (int64_t)a * step;
+    }
+    // nine ways at a time: eight reads in flight per round
+    while (hi - lo > 8) {
+      const int64_t step = (hi - lo + 8) / 9;
+      int below = 0;
+      int64_t q[8];
+      double v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        q[k] = lo + (int64_t)(k + 1) * step - 1;
+        v[k] = q[k] < hi ? cdf[q[k]] : INFINITY;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) below += (U > v[k]) ? 1 : 0;       // (ascending: the places below U come first)
+      int64_t nlo = lo, nhi = hi;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (k == below - 1) nlo = q[k] + 1;
+        if (k == below && q[k] < hi) nhi = q[k];
+      }
+      lo = nlo; hi = nhi;
+    }
+    {
+      int below = 0;
+      double v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = lo + k < hi ? cdf[lo + k] : INFINITY;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) below += (U > v[k]) ? 1 : 0;
+      lo = lo + below;
+    }
+  }
+  if (m >= n) return;
   if (lo > n - 1) lo = n - 1;
   idx[m] = lo;
   x2[m] = x[lo];
