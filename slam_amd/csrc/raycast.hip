@@ -59,6 +59,9 @@ constexpr int kCapSpan = 16;
 constexpr int cap_buckets(int cap) { int n = 1; while (n < 2 * cap) n <<= 1; return n; }
 constexpr int kEdgeQueue = 32;        // cells on a sector edge that a particle can park (interval path); more: the particle is done entry by entry
 constexpr int kEdgeQueueWide = 64;    // ... in the interval-only kernel, whose queue also takes the unused part of the ring (see edgeq)
+#ifndef MCL_GRID_WAYS
+#define MCL_GRID_WAYS 2
+#endif
 constexpr int kSubLists = 64;         // the list of left-over particles is kept as this many lists with a counter each (blocks b, b + 64, ... share one)
 constexpr int kFiled = 16;            // particles an interval-only wave notes before it appends them to the list in one go
 constexpr int kSeamSlots = 64;        // beams near the seam of the bearings whose cells there are asked one by one (interval-only kernel, headings outside the circular range)
@@ -1190,27 +1193,49 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
         emin[k] = (unsigned long long)__double_as_longlong(entry_px((int)(ck & 0x3ffu), z, eta));
       };
       int waiting = 0;
-      for (int k0 = 0; k0 < NE; k0 += 64) {
-        const int k = k0 + lane;
-        bool own = false;
-        if (k < NE) {
-          const unsigned int ck = s_cls[k];
-          const int cc = (int)(ck >> 20);
-          const double z = __longlong_as_double((long long)rmin[zoff + cc]);
-          const unsigned long long me = emin[k];
-          own = (me != r2max_bits) && (__longlong_as_double((long long)me) <= z * z * (1.0 + 1e-15));
-          if (!own) emin[k] = (unsigned long long)__double_as_longlong(entry_px((int)(ck & 0x3ffu), z, etac[cc]));   // in place: the minimum is spent
+      // two entries per lane and round, in straight-line code (an entry beyond the table computes the last one's value and
+      // drops it, one that waits for its own range computes its class's and drops it): the two chains of float64
+      // arithmetic -- an exponential and a division each -- overlap, which four waves per SIMD alone do not hide
+      constexpr int kWays = MCL_GRID_WAYS;
+      for (int k0 = 0; k0 < NE; k0 += 64 * kWays) {
+        int kk[kWays];
+        unsigned int ck[kWays];
+        double zz[kWays], ee[kWays], px[kWays];
+        bool own[kWays];
+#pragma unroll
+        for (int u = 0; u < kWays; ++u) {
+          kk[u] = k0 + 64 * u + lane;
+          const int j = kk[u] < NE ? kk[u] : NE - 1;
+          ck[u] = s_cls[j];
+          const int cc = (int)(ck[u] >> 20);
+          zz[u] = __longlong_as_double((long long)rmin[zoff + cc]);
+          ee[u] = etac[cc];
+          const unsigned long long me = emin[j];
+          own[u] = kk[u] < NE && (me != r2max_bits) && (__longlong_as_double((long long)me) <= zz[u] * zz[u] * (1.0 + 1e-15));
         }
-        const unsigned long long om = __ballot(own);
-        if (own) {
-          const unsigned int pos = __builtin_amdgcn_mbcnt_hi((unsigned int)(om >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)om, 0u));
-          ring[waiting + (int)pos] = (unsigned int)k;
-        }
-        waiting += __popcll(om);
-        if (waiting >= 64) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          own_range(ring[waiting - 64 + lane]);
-          waiting -= 64;
+#pragma unroll
+        for (int u = 0; u < kWays; ++u) px[u] = entry_px((int)(ck[u] & 0x3ffu), zz[u], ee[u]);
+#pragma unroll
+        for (int u = 0; u < kWays; ++u)
+          if (kk[u] < NE && !own[u]) emin[kk[u]] = (unsigned long long)__double_as_longlong(px[u]);   // in place: the minimum is spent
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < kWays; ++u) any = any || own[u];
+        if (__ballot(any) != 0ull) {
+#pragma unroll
+          for (int u = 0; u < kWays; ++u) {
+            const unsigned long long om = __ballot(own[u]);
+            if (own[u]) {
+              const unsigned int pos = __builtin_amdgcn_mbcnt_hi((unsigned int)(om >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)om, 0u));
+              ring[waiting + (int)pos] = (unsigned int)kk[u];
+            }
+            waiting += __popcll(om);
+            if (waiting >= 64) {          // (the ring holds 128)
+              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+              own_range(ring[waiting - 64 + lane]);
+              waiting -= 64;
+            }
+          }
         }
       }
       if (waiting > 0) {
