@@ -958,6 +958,11 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
           }
         }
         if (nq > 0) {
+          // (histogram filter: what a parked cell's lane works out -- squared distance, exact bearing, the classes at its
+          // edge -- for the pass over the classes' entries below)
+          unsigned long long g_r2bits = 0ull;
+          double g_exact = 0.0;
+          unsigned int g_ends = 0u, g_prev = 0u;
           if (lane < nq && lane < EQ) {
             const unsigned long long q = edgeq[lane];
             const unsigned int e = (unsigned int)q;
@@ -1027,30 +1032,72 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
               // an entry accepts goes to the entry's own minimum.  The class that ends at the edge, the one that
               // starts there, and the one that holds the edge in its interior (sectors span two intervals at most:
               // it is the class whose sector starts an interval earlier), which accepts without being asked.
-              auto give = [&](unsigned int cc, bool ask) {
-                for (int mm = s_first[cc]; mm < s_first[cc + 1]; ++mm) {
-                  const unsigned int me = s_member[mm], ck = s_cls[me];
-                  bool ok = true;
-                  if (ask) {
-                    const double beta = s_ang[ck & 0x3ffu] + s_ang[P.g_B0 + ((ck >> 10) & 0x3ffu)];   // robot.py:252
-                    const double de = fabs((beta + th) - a_exact);
-                    ok = (de <= P.half) || (de >= P.two_pi_lo && de <= P.two_pi_hi);
-                  }
-                  if (ok) atomicMin(&emin[me], r2bits);
-                }
-              };
-              if ((ends >> 10) & 1u) give(ends & 0x3ffu, true);
-              if ((ends >> 21) & 1u) give((ends >> 11) & 0x3ffu, true);
-              if ((ends >> 22) & 1u) {
-                const unsigned int prev = s_ivends[left];
-                if ((prev >> 21) & 1u) give((prev >> 11) & 0x3ffu, false);
-              }
+              // Done below, a parked cell at a time with the lanes on the entries: sixteen lanes for each of the three
+              // classes (a lane per parked cell walking its 39 entries one after the other cost three times as much).
+              g_r2bits = r2bits; g_exact = a_exact; g_ends = ends; g_prev = s_ivends[left];
             } else if (!at_seam) {
             const bool no_end = ((ends >> 10) & 1u) && refuses(ends & 0x3ffu);
             const bool no_start = ((ends >> 21) & 1u) && refuses((ends >> 11) & 0x3ffu);
             if (!no_end) atomicMin(&imin[left], r2bits);
             else if (no_start && ((ends >> 22) & 1u)) lane_redo = true;
             if (!no_start) atomicMin(&imin[right], r2bits);
+            }
+          }
+          if constexpr (GRID) {
+            const int role = lane >> 4, slot = lane & 15;
+            const int n_parked = nq < EQ ? nq : EQ;
+            const long long eb = __double_as_longlong(g_exact);
+            // what lane q worked out, and this lane's class of it: the class that ends at the edge, the one that starts
+            // there, and the one that holds the edge in its interior (the class whose sector starts an interval
+            // earlier), which accepts without being asked
+            auto cell_of = [&](int q, unsigned long long& rb, double& ax, unsigned int& cc) -> bool {
+              const unsigned int ends = (unsigned int)__builtin_amdgcn_readlane((int)g_ends, q);
+              const unsigned int prev = (unsigned int)__builtin_amdgcn_readlane((int)g_prev, q);
+              rb = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(g_r2bits >> 32), q) << 32) |
+                   (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)g_r2bits, q);
+              ax = __longlong_as_double((long long)(((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(eb >> 32), q) << 32) |
+                                                    (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)eb, q)));
+              const bool en0 = ((ends >> 10) & 1u) != 0u, en1 = ((ends >> 21) & 1u) != 0u;
+              const bool en2 = ((ends >> 22) & 1u) != 0u && ((prev >> 21) & 1u) != 0u;
+              cc = role == 0 ? (ends & 0x3ffu) : (role == 1 ? ((ends >> 11) & 0x3ffu) : ((prev >> 11) & 0x3ffu));
+              return role == 0 ? en0 : (role == 1 ? en1 : (role == 2 ? en2 : false));
+            };
+            auto accepts = [&](unsigned int me, double ax) -> bool {
+              const unsigned int ck = s_cls[me];
+              const double beta = s_ang[ck & 0x3ffu] + s_ang[P.g_B0 + ((ck >> 10) & 0x3ffu)];   // robot.py:252
+              const double de = fabs((beta + th) - ax);
+              return role == 2 || (de <= P.half) || (de >= P.two_pi_lo && de <= P.two_pi_hi);
+            };
+            // two parked cells per round, in straight-line code: each is a chain of four dependent LDS reads, and two
+            // chains overlap
+#pragma unroll 1
+            for (int q = 0; q < n_parked; q += 2) {
+              const int q1 = q + 1 < n_parked ? q + 1 : q;
+              unsigned long long rb_a, rb_b;
+              double ax_a, ax_b;
+              unsigned int cc_a, cc_b;
+              const bool en_a = cell_of(q, rb_a, ax_a, cc_a);
+              const bool en_b = cell_of(q1, rb_b, ax_b, cc_b) && q1 != q;
+              const int mm_a = (int)s_first[cc_a] + slot, end_a = (int)s_first[cc_a + 1];
+              const int mm_b = (int)s_first[cc_b] + slot, end_b = (int)s_first[cc_b + 1];
+              const bool v_a = en_a && mm_a < end_a, v_b = en_b && mm_b < end_b;
+              const unsigned int me_a = s_member[v_a ? mm_a : 0], me_b = s_member[v_b ? mm_b : 0];
+              const bool ok_a = accepts(me_a, ax_a), ok_b = accepts(me_b, ax_b);
+              if (v_a && ok_a) atomicMin(&emin[me_a], rb_a);
+              if (v_b && ok_b) atomicMin(&emin[me_b], rb_b);
+              // (classes of more than sixteen entries: the rest, one after the other)
+              if (__ballot((en_a && mm_a + 16 < end_a) || (en_b && mm_b + 16 < end_b)) != 0ull) {
+                if (en_a)
+                  for (int mm = mm_a + 16; mm < end_a; mm += 16) {
+                    const unsigned int me = s_member[mm];
+                    if (accepts(me, ax_a)) atomicMin(&emin[me], rb_a);
+                  }
+                if (en_b)
+                  for (int mm = mm_b + 16; mm < end_b; mm += 16) {
+                    const unsigned int me = s_member[mm];
+                    if (accepts(me, ax_b)) atomicMin(&emin[me], rb_b);
+                  }
+              }
             }
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1063,6 +1110,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
     }
 
     // ranges -> beam mixture -> weight
+    if constexpr (GRID) STAMP(1);   // (histogram filter: the parked cells, apart from the mixtures)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (use_iv) {
       for (int k = lane; k < P.iv_cmax; k += 64) imin[IVN + k] = imin[k];
@@ -1192,6 +1240,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
         if (zo < z) { z = zo; eta = 1.0 / (1.0 - exp(-P.lambda * z)); }
         emin[k] = (unsigned long long)__double_as_longlong(entry_px((int)(ck & 0x3ffu), z, eta));
       };
+      STAMP(4);   // (histogram filter: class ranges and normalisers)
       int waiting = 0;
       // two entries per lane and round, in straight-line code (an entry beyond the table computes the last one's value and
       // drops it, one that waits for its own range computes its class's and drops it): the two chains of float64
