@@ -962,7 +962,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
           // edge -- for the pass over the classes' entries below)
           unsigned long long g_r2bits = 0ull;
           double g_exact = 0.0;
-          unsigned int g_ends = 0u, g_prev = 0u;
+          unsigned int g_ends = 0u;
           if (lane < nq && lane < EQ) {
             const unsigned long long q = edgeq[lane];
             const unsigned int e = (unsigned int)q;
@@ -1034,7 +1034,13 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
               // it is the class whose sector starts an interval earlier), which accepts without being asked.
               // Done below, a parked cell at a time with the lanes on the entries: sixteen lanes for each of the three
               // classes (a lane per parked cell walking its 39 entries one after the other cost three times as much).
-              g_r2bits = r2bits; g_exact = a_exact; g_ends = ends; g_prev = s_ivends[left];
+              g_r2bits = r2bits; g_exact = a_exact; g_ends = ends;
+              // (the class that holds the edge inside accepts without being asked -- every entry of it --: the cell goes
+              // to a minimum of that class, kept where the class's normaliser will stand, instead of to its entries')
+              if ((ends >> 22) & 1u) {
+                const unsigned int prev = s_ivends[left];
+                if ((prev >> 21) & 1u) atomicMin(emin + NE + ((prev >> 11) & 0x3ffu), r2bits);
+              }
             } else if (!at_seam) {
             const bool no_end = ((ends >> 10) & 1u) && refuses(ends & 0x3ffu);
             const bool no_start = ((ends >> 21) & 1u) && refuses((ends >> 11) & 0x3ffu);
@@ -1044,40 +1050,41 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
             }
           }
           if constexpr (GRID) {
-            const int role = lane >> 4, slot = lane & 15;
+            // sixteen lanes on the entries of the class that ends at a parked cell's edge, sixteen on the class that
+            // starts there; each half of the wave has a parked cell of its own, and two such pairs go through a round in
+            // straight-line code (each is a chain of four dependent LDS reads: two chains overlap)
+            const int role = (lane >> 4) & 1, slot = lane & 15;
+            const bool upper = lane >= 32;
             const int n_parked = nq < EQ ? nq : EQ;
             const long long eb = __double_as_longlong(g_exact);
-            // what lane q worked out, and this lane's class of it: the class that ends at the edge, the one that starts
-            // there, and the one that holds the edge in its interior (the class whose sector starts an interval
-            // earlier), which accepts without being asked
-            auto cell_of = [&](int q, unsigned long long& rb, double& ax, unsigned int& cc) -> bool {
-              const unsigned int ends = (unsigned int)__builtin_amdgcn_readlane((int)g_ends, q);
-              const unsigned int prev = (unsigned int)__builtin_amdgcn_readlane((int)g_prev, q);
-              rb = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(g_r2bits >> 32), q) << 32) |
-                   (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)g_r2bits, q);
-              ax = __longlong_as_double((long long)(((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(eb >> 32), q) << 32) |
-                                                    (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)eb, q)));
-              const bool en0 = ((ends >> 10) & 1u) != 0u, en1 = ((ends >> 21) & 1u) != 0u;
-              const bool en2 = ((ends >> 22) & 1u) != 0u && ((prev >> 21) & 1u) != 0u;
-              cc = role == 0 ? (ends & 0x3ffu) : (role == 1 ? ((ends >> 11) & 0x3ffu) : ((prev >> 11) & 0x3ffu));
-              return role == 0 ? en0 : (role == 1 ? en1 : (role == 2 ? en2 : false));
+            auto pick = [&](int v, int qa, int qb) -> unsigned int {      // what lane qa (lower half) / qb (upper half) holds
+              const int a = __builtin_amdgcn_readlane(v, qa), b = __builtin_amdgcn_readlane(v, qb);
+              return (unsigned int)(upper ? b : a);
+            };
+            auto cell_of = [&](int qa, int qb, unsigned long long& rb, double& ax, unsigned int& cc) -> bool {
+              const unsigned int ends = pick((int)g_ends, qa, qb);
+              rb = ((unsigned long long)pick((int)(g_r2bits >> 32), qa, qb) << 32) | (unsigned long long)pick((int)g_r2bits, qa, qb);
+              ax = __longlong_as_double((long long)(((unsigned long long)pick((int)(eb >> 32), qa, qb) << 32) |
+                                                    (unsigned long long)pick((int)eb, qa, qb)));
+              cc = role == 0 ? (ends & 0x3ffu) : ((ends >> 11) & 0x3ffu);
+              return (upper ? qb : qa) < n_parked && (role == 0 ? ((ends >> 10) & 1u) != 0u : ((ends >> 21) & 1u) != 0u);
             };
             auto accepts = [&](unsigned int me, double ax) -> bool {
               const unsigned int ck = s_cls[me];
               const double beta = s_ang[ck & 0x3ffu] + s_ang[P.g_B0 + ((ck >> 10) & 0x3ffu)];   // robot.py:252
               const double de = fabs((beta + th) - ax);
-              return role == 2 || (de <= P.half) || (de >= P.two_pi_lo && de <= P.two_pi_hi);
+              return (de <= P.half) || (de >= P.two_pi_lo && de <= P.two_pi_hi);
             };
-            // two parked cells per round, in straight-line code: each is a chain of four dependent LDS reads, and two
-            // chains overlap
+            const int q_last = n_parked - 1;
 #pragma unroll 1
-            for (int q = 0; q < n_parked; q += 2) {
-              const int q1 = q + 1 < n_parked ? q + 1 : q;
+            for (int q = 0; q < n_parked; q += 4) {
               unsigned long long rb_a, rb_b;
               double ax_a, ax_b;
               unsigned int cc_a, cc_b;
-              const bool en_a = cell_of(q, rb_a, ax_a, cc_a);
-              const bool en_b = cell_of(q1, rb_b, ax_b, cc_b) && q1 != q;
+              // (a lane index past the parked cells is read as the last one's and disabled)
+              const bool en_a = cell_of(q, q + 1 < n_parked ? q + 1 : q_last, rb_a, ax_a, cc_a) && (!upper || q + 1 < n_parked);
+              const bool en_b = cell_of(q + 2 < n_parked ? q + 2 : q_last, q + 3 < n_parked ? q + 3 : q_last, rb_b, ax_b, cc_b) &&
+                                (upper ? q + 3 < n_parked : q + 2 < n_parked);
               const int mm_a = (int)s_first[cc_a] + slot, end_a = (int)s_first[cc_a + 1];
               const int mm_b = (int)s_first[cc_b] + slot, end_b = (int)s_first[cc_b + 1];
               const bool v_a = en_a && mm_a < end_a, v_b = en_b && mm_b < end_b;
@@ -1209,7 +1216,11 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
       // intervals stood: every class reads first -- the roots wait in the other array meanwhile)
       const int zoff = use_iv ? 0 : G;
       if (use_iv) {
-        for (int cc = lane; cc < B; cc += 64) etac[cc] = sqrt(__longlong_as_double((long long)beam_r2bits(cc)));   // robot.py:269
+        for (int cc = lane; cc < B; cc += 64) {
+          // (the class's own minimum: parked cells that its sector holds inside, see above)
+          const unsigned long long held = reinterpret_cast<const unsigned long long*>(etac)[cc], spans = beam_r2bits(cc);
+          etac[cc] = sqrt(__longlong_as_double((long long)(held < spans ? held : spans)));   // robot.py:269
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
       for (int cc = lane; cc < B; cc += 64) {
