@@ -39,10 +39,12 @@
 //
 // Compiled with -ffp-contract=off.
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 
 #include "device_rng.h"
 #include "mclhip_internal.h"
+#include "exp_nonpos.h"
 
 namespace mcl {
 
@@ -1225,90 +1227,103 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
       }
       for (int cc = lane; cc < B; cc += 64) {
         const double z = use_iv ? etac[cc] : sqrt(__longlong_as_double((long long)rmin[G + cc]));   // robot.py:269
-        etac[cc] = 1.0 / (1.0 - exp(-P.lambda * z));
+        etac[cc] = 1.0 / (1.0 - exp_nonpos(-P.lambda * z));
         rmin[zoff + cc] = (unsigned long long)__double_as_longlong(z);
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       // p(z_meas | z_pred) of one entry (range_sensor.py:95-112 called from robot.py:297)
-      auto entry_px = [&](int kb, double z, double eta) -> double {
-        const double xm = s_zt[kb];
-        const bool in_range = (0.0 <= xm) && (xm <= P.z_max);
-        const double d = xm - z;
-        const double p_hit = in_range ? P.c_hit * exp(-0.5 * (d * d) / P.sigma2) : 0.0;
-        const double p_short = ((0.0 <= xm) && (xm <= z)) ? eta * P.lambda * s_el[kb] : 0.0;   // exp(-lambda * z_meas) tabulated per beam
-        const double p_max = (fabs(xm - P.z_max) < 1e-6) ? 1.0 : 0.0;
-        const double p_rand = in_range ? P.p_rand : 0.0;
-        return p_hit * P.w_hit + p_short * P.w_short + p_max * P.w_max + p_rand * P.w_rand;
-      };
-      // entries whose own minimum may undercut their class wait in the ring and are done together, so the
-      // common case stays free of the root / exponential / division they need
-      auto own_range = [&](unsigned int k) {
-        const unsigned int ck = s_cls[k];
-        const int cc = (int)(ck >> 20);
-        double z = __longlong_as_double((long long)rmin[zoff + cc]);
-        double eta = etac[cc];
-        const double zo = sqrt(__longlong_as_double((long long)emin[k]));
-        if (zo < z) { z = zo; eta = 1.0 / (1.0 - exp(-P.lambda * z)); }
-        emin[k] = (unsigned long long)__double_as_longlong(entry_px((int)(ck & 0x3ffu), z, eta));
-      };
-      STAMP(4);   // (histogram filter: class ranges and normalisers)
-      int waiting = 0;
-      // two entries per lane and round, in straight-line code (an entry beyond the table computes the last one's value and
-      // drops it, one that waits for its own range computes its class's and drops it): the two chains of float64
-      // arithmetic -- an exponential and a division each -- overlap, which four waves per SIMD alone do not hide
-      constexpr int kWays = MCL_GRID_WAYS;
-      for (int k0 = 0; k0 < NE; k0 += 64 * kWays) {
-        int kk[kWays];
-        unsigned int ck[kWays];
-        double zz[kWays], ee[kWays], px[kWays];
-        bool own[kWays];
-#pragma unroll
-        for (int u = 0; u < kWays; ++u) {
-          kk[u] = k0 + 64 * u + lane;
-          const int j = kk[u] < NE ? kk[u] : NE - 1;
-          ck[u] = s_cls[j];
-          const int cc = (int)(ck[u] >> 20);
-          zz[u] = __longlong_as_double((long long)rmin[zoff + cc]);
-          ee[u] = etac[cc];
-          const unsigned long long me = emin[j];
-          own[u] = kk[u] < NE && (me != r2max_bits) && (__longlong_as_double((long long)me) <= zz[u] * zz[u] * (1.0 + 1e-15));
-        }
-#pragma unroll
-        for (int u = 0; u < kWays; ++u) px[u] = entry_px((int)(ck[u] & 0x3ffu), zz[u], ee[u]);
-#pragma unroll
-        for (int u = 0; u < kWays; ++u)
-          if (kk[u] < NE && !own[u]) emin[kk[u]] = (unsigned long long)__double_as_longlong(px[u]);   // in place: the minimum is spent
-        bool any = false;
-#pragma unroll
-        for (int u = 0; u < kWays; ++u) any = any || own[u];
-        if (__ballot(any) != 0ull) {
-#pragma unroll
+      // (without branches, so that two entries' chains can be interleaved: the exponential is taken whatever the range
+      // test says -- exp_nonpos and div_by give the bits of exp and of the division, with fewer instructions)
+      const DivBy by_sigma2 = make_div_by(P.sigma2);
+      // (the mixtures once for a divisor of ordinary size and once for any other: a test inside the loop, uniform as it
+      // is, would cut the loop's body into blocks and keep the two entries' chains apart)
+      auto likelihoods = [&](auto fast_div_tag) {
+        constexpr bool kFastDiv = decltype(fast_div_tag)::value;
+        auto entry_px = [&](int kb, double z, double eta) -> double {
+          const double xm = s_zt[kb];
+          const double el = s_el[kb];                              // exp(-lambda * z_meas) tabulated per beam
+          const bool in_range = (0.0 <= xm) && (xm <= P.z_max);
+          const double d = xm - z;
+          const double num = -0.5 * (d * d);
+          double e_hit = exp_nonpos(kFastDiv ? div_by(num, by_sigma2) : num / P.sigma2);
+          asm volatile("" : "+v"(e_hit));   // (taken here: not moved under a branch on the range test, where the second entry's chain could not join it)
+          const double p_hit = in_range ? P.c_hit * e_hit : 0.0;
+          const double p_short = ((0.0 <= xm) && (xm <= z)) ? eta * P.lambda * el : 0.0;
+          const double p_max = (fabs(xm - P.z_max) < 1e-6) ? 1.0 : 0.0;
+          const double p_rand = in_range ? P.p_rand : 0.0;
+          return p_hit * P.w_hit + p_short * P.w_short + p_max * P.w_max + p_rand * P.w_rand;
+        };
+        // entries whose own minimum may undercut their class wait in the ring and are done together, so the
+        // common case stays free of the root / exponential / division they need
+        auto own_range = [&](unsigned int k) {
+          const unsigned int ck = s_cls[k];
+          const int cc = (int)(ck >> 20);
+          double z = __longlong_as_double((long long)rmin[zoff + cc]);
+          double eta = etac[cc];
+          const double zo = sqrt(__longlong_as_double((long long)emin[k]));
+          if (zo < z) { z = zo; eta = 1.0 / (1.0 - exp_nonpos(-P.lambda * z)); }
+          emin[k] = (unsigned long long)__double_as_longlong(entry_px((int)(ck & 0x3ffu), z, eta));
+        };
+        STAMP(4);   // (histogram filter: class ranges and normalisers)
+        int waiting = 0;
+        // two entries per lane and round, in straight-line code (an entry beyond the table computes the last one's value and
+        // drops it, one that waits for its own range computes its class's and drops it): the two chains of float64
+        // arithmetic -- an exponential and a division each -- overlap, which four waves per SIMD alone do not hide
+        constexpr int kWays = MCL_GRID_WAYS;
+        for (int k0 = 0; k0 < NE; k0 += 64 * kWays) {
+          int kk[kWays];
+          unsigned int ck[kWays];
+          double zz[kWays], ee[kWays], px[kWays];
+          bool own[kWays];
+  #pragma unroll
           for (int u = 0; u < kWays; ++u) {
-            const unsigned long long om = __ballot(own[u]);
-            if (own[u]) {
-              const unsigned int pos = __builtin_amdgcn_mbcnt_hi((unsigned int)(om >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)om, 0u));
-              ring[waiting + (int)pos] = (unsigned int)kk[u];
-            }
-            waiting += __popcll(om);
-            if (waiting >= 64) {          // (the ring holds 128)
-              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-              own_range(ring[waiting - 64 + lane]);
-              waiting -= 64;
+            kk[u] = k0 + 64 * u + lane;
+            const int j = kk[u] < NE ? kk[u] : NE - 1;
+            ck[u] = s_cls[j];
+            const int cc = (int)(ck[u] >> 20);
+            zz[u] = __longlong_as_double((long long)rmin[zoff + cc]);
+            ee[u] = etac[cc];
+            const unsigned long long me = emin[j];
+            own[u] = kk[u] < NE && (me != r2max_bits) && (__longlong_as_double((long long)me) <= zz[u] * zz[u] * (1.0 + 1e-15));
+          }
+  #pragma unroll
+          for (int u = 0; u < kWays; ++u) px[u] = entry_px((int)(ck[u] & 0x3ffu), zz[u], ee[u]);
+  #pragma unroll
+          for (int u = 0; u < kWays; ++u)
+            if (kk[u] < NE && !own[u]) emin[kk[u]] = (unsigned long long)__double_as_longlong(px[u]);   // in place: the minimum is spent
+          bool any = false;
+  #pragma unroll
+          for (int u = 0; u < kWays; ++u) any = any || own[u];
+          if (__ballot(any) != 0ull) {
+  #pragma unroll
+            for (int u = 0; u < kWays; ++u) {
+              const unsigned long long om = __ballot(own[u]);
+              if (own[u]) {
+                const unsigned int pos = __builtin_amdgcn_mbcnt_hi((unsigned int)(om >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)om, 0u));
+                ring[waiting + (int)pos] = (unsigned int)kk[u];
+              }
+              waiting += __popcll(om);
+              if (waiting >= 64) {          // (the ring holds 128)
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                own_range(ring[waiting - 64 + lane]);
+                waiting -= 64;
+              }
             }
           }
         }
-      }
-      if (waiting > 0) {
+        if (waiting > 0) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          if (lane < waiting) own_range(ring[lane]);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (lane < waiting) own_range(ring[lane]);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      const int64_t cell = P.g_cell[p];
-      for (int d = lane; d < P.g_D; d += 64) {
-        double q = 1.0;   // q *= p_k in beam order (robot.py:295-298)
-        for (int k = 0; k < P.g_B0; ++k) q = q * __longlong_as_double((long long)emin[d * P.g_B0 + k]);
-        P.g_pk[cell * P.g_D + d] = (float)(P.g_pk_pred[cell * P.g_D + d] * q);   // robot.py:300, float32 store
-      }
+        const int64_t cell = P.g_cell[p];
+        for (int d = lane; d < P.g_D; d += 64) {
+          double q = 1.0;   // q *= p_k in beam order (robot.py:295-298)
+          for (int k = 0; k < P.g_B0; ++k) q = q * __longlong_as_double((long long)emin[d * P.g_B0 + k]);
+          P.g_pk[cell * P.g_D + d] = (float)(P.g_pk_pred[cell * P.g_D + d] * q);   // robot.py:300, float32 store
+        }
+      };
+      if (by_sigma2.usable) likelihoods(std::true_type{}); else likelihoods(std::false_type{});
     } else if constexpr (FAST) {
       // range_sensor.py:31-112 per beam, float32 (see the comment at the template head).  What is exact:
       //   0 <= z <= z_max holds for every entry (r2 <= z_max^2 by construction), so p_hit and p_rand always apply;
