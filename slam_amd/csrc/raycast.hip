@@ -1448,8 +1448,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
         } else {
           // range_sensor.py:31-67, operation by operation
           const double d = zd - ztd;
-          const double p_hit = in_range ? P.c_hit * exp(-0.5 * (d * d) / P.sigma2) : 0.0;
-          const double p_short = in_short ? s_el[k] * exp(-P.lambda * zd) : 0.0;
+          // (exp_nonpos: the bits of exp for the arguments that count here, none of which is positive)
+          const double p_hit = in_range ? P.c_hit * exp_nonpos(-0.5 * (d * d) / P.sigma2) : 0.0;
+          const double p_short = in_short ? s_el[k] * exp_nonpos(-P.lambda * zd) : 0.0;
           const double p_max = (fabs(zd - P.z_max) < 1e-6) ? 1.0 : 0.0;
           const double p_rand = in_range ? P.p_rand : 0.0;
           pkd = p_hit * P.w_hit + p_short * P.w_short + p_max * P.w_max + p_rand * P.w_rand;

@@ -4,6 +4,7 @@
 //
 // Compiled with -ffp-contract=off.
 #include "mclhip_internal.h"
+#include "exp_nonpos.h"
 
 namespace mcl {
 
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(512) void chunk_sum_kernel(double* __restrict__ w, 
   const double mx = FROM_LOG ? scal[1] : 0.0;
   auto weight = [&](int64_t i) -> double {
     if constexpr (FROM_LOG) {
-      const double v = (mx == -INFINITY) ? 0.0 : exp(logw[i] - mx);
+      const double v = (mx == -INFINITY) ? 0.0 : exp_nonpos(logw[i] - mx);
       w[i] = v;
       return v;
     } else {
@@ -638,7 +639,7 @@ __global__ __launch_bounds__(512) void chunk_tile_sum_kernel(double* __restrict_
   }
   auto weight = [&](int64_t i) -> double {
     if constexpr (FROM_LOG) {
-      const double v = (mx == -INFINITY) ? 0.0 : exp(logw[i] - mx);
+      const double v = (mx == -INFINITY) ? 0.0 : exp_nonpos(logw[i] - mx);
       w[i] = v;
       return v;
     } else {
@@ -1019,7 +1020,7 @@ __global__ void divide_by_kernel(double* __restrict__ w, int64_t n, double total
 __global__ void exp_shift_by_kernel(const double* __restrict__ logw, double* __restrict__ w, int64_t n, double mx) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  w[i] = (mx == -INFINITY) ? 0.0 : exp(logw[i] - mx);
+  w[i] = (mx == -INFINITY) ? 0.0 : exp_nonpos(logw[i] - mx);
 }
 
 int launch_shard_max_logw(mclhip_ctx* c, double* d_also) {
