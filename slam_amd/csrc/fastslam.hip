@@ -32,6 +32,7 @@
 
 #include "device_rng.h"
 #include "mclhip_internal.h"
+#include "libm_bits.h"
 
 namespace mcl {
 
@@ -93,15 +94,18 @@ __device__ inline M2 inv_lu(const M2& m, double* det) {
   const bool swap = fabs(m.c) > fabs(m.a);
   const double p0 = swap ? m.c : m.a, p1 = swap ? m.d : m.b;   // pivot row
   const double r0 = swap ? m.a : m.c, r1 = swap ? m.b : m.d;
-  const double l = r0 / p0;
+  // (three quotients by the pivot and two by u11: the reciprocal of each formed once, see DivBy -- the same bits)
+  const DivBy by_p0 = make_div_by(p0);
+  const double l = div_by_checked(r0, by_p0);
   const double u11 = r1 - l * p1;
+  const DivBy by_u11 = make_div_by(u11);
   if (det) *det = swap ? -(p0 * u11) : (p0 * u11);
   // solve for the two columns of the (row-permuted) identity
   const double b0a = swap ? 0.0 : 1.0, b1a = swap ? 1.0 : 0.0;   // column 0
   const double b0b = swap ? 1.0 : 0.0, b1b = swap ? 0.0 : 1.0;   // column 1
   const double y1a = b1a - l * b0a, y1b = b1b - l * b0b;
-  const double x1a = y1a / u11, x1b = y1b / u11;
-  const double x0a = (b0a - p1 * x1a) / p0, x0b = (b0b - p1 * x1b) / p0;
+  const double x1a = div_by_checked(y1a, by_u11), x1b = div_by_checked(y1b, by_u11);
+  const double x0a = div_by_checked(b0a - p1 * x1a, by_p0), x0b = div_by_checked(b0b - p1 * x1b, by_p0);
   return M2{x0a, x0b, x1a, x1b};
 }
 
@@ -110,11 +114,12 @@ __device__ inline void predict_measurement(double m0, double m1, double x, doubl
   const double dx = m0 - x, dy = m1 - y;
   const double q = dx * dx + dy * dy;
   const double rr = sqrt(q);
-  double ph = atan2(dy, dx) - th;             // :213
+  double ph = atan2_bits(dy, dx) - th;        // :213
   if (ph > M_PI) ph -= M_PI * 2;
   else if (ph < -M_PI) ph += M_PI * 2;
   *r = rr; *phi = ph;
-  *H = M2{dx / rr, dy / rr, -dy / q, dx / q}; // :233-236
+  const DivBy by_rr = make_div_by(rr), by_q = make_div_by(q);
+  *H = M2{div_by_checked(dx, by_rr), div_by_checked(dy, by_rr), div_by_checked(-dy, by_q), div_by_checked(dx, by_q)}; // :233-236
 }
 
 __device__ inline double wrap_residual(double d) {

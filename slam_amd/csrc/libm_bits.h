@@ -37,6 +37,45 @@ __device__ __forceinline__ double exp_nonpos(double x) {
   return (x < -1075.0) ? 0.0 : v;
 }
 
+// atan2(y, x), bit for bit the device library's: the quotient of the smaller by the larger magnitude, a degree-19
+// polynomial in its square, the fix-ups by octant and the special values -- with three-operand fused multiply-adds
+// (see fma3: the library's nineteen coefficients cost a 64-bit move each where they live in registers across a loop).
+__device__ __forceinline__ double atan2_bits(double y, double x) {
+  const double ax = __builtin_fabs(x), ay = __builtin_fabs(y);
+  const double v = __builtin_fmax(ax, ay), u = __builtin_fmin(ax, ay);
+  const double q = u / v;
+  const double s = q * q;
+  double p = fma3(s, __longlong_as_double(0x3eeba404b5e68a13ll), __longlong_as_double((long long)0xbf23e260bd3237f4ull));
+  p = fma3(s, p, __longlong_as_double(0x3f4b2bb069efb384ll));
+  p = fma3(s, p, __longlong_as_double((long long)0xbf67952daf56de9bull));
+  p = fma3(s, p, __longlong_as_double(0x3f7d6d43a595c56fll));
+  p = fma3(s, p, __longlong_as_double((long long)0xbf8c6ea4a57d9582ull));
+  p = fma3(s, p, __longlong_as_double(0x3f967e295f08b19fll));
+  p = fma3(s, p, __longlong_as_double((long long)0xbf9e9ae6fc27006aull));
+  p = fma3(s, p, __longlong_as_double(0x3fa2c15b5711927all));
+  p = fma3(s, p, __longlong_as_double((long long)0xbfa59976e82d3ff0ull));
+  p = fma3(s, p, __longlong_as_double(0x3fa82d5d6ef28734ll));
+  p = fma3(s, p, __longlong_as_double((long long)0xbfaae5ce6a214619ull));
+  p = fma3(s, p, __longlong_as_double(0x3fae1bb48427b883ll));
+  p = fma3(s, p, __longlong_as_double((long long)0xbfb110e48b207f05ull));
+  p = fma3(s, p, __longlong_as_double(0x3fb3b13657b87036ll));
+  p = fma3(s, p, __longlong_as_double((long long)0xbfb745d119378e4full));
+  p = fma3(s, p, __longlong_as_double(0x3fbc71c717e1913cll));
+  p = fma3(s, p, __longlong_as_double((long long)0xbfc2492492376b7dull));
+  p = fma3(s, p, __longlong_as_double(0x3fc99999999952ccll));
+  p = fma3(s, p, __longlong_as_double((long long)0xbfd5555555555523ull));
+  const double t = s * p;
+  double a = __builtin_fma(q, t, q);
+  const double half_pi = __longlong_as_double(0x3ff921fb54442d18ll), pi = __longlong_as_double(0x400921fb54442d18ll);
+  const bool x_neg = __double_as_longlong(x) < 0;
+  if (ax < ay) a = half_pi - a;
+  if (x_neg) a = pi - a;
+  if (y == 0.0) a = x_neg ? pi : 0.0;
+  if (__builtin_isinf(x) && __builtin_isinf(y)) a = x_neg ? __longlong_as_double(0x4002d97c7f3321d2ll) : __longlong_as_double(0x3fe921fb54442d18ll);
+  if (x != x || y != y) a = __longlong_as_double(0x7ff8000000000000ll);
+  return __builtin_copysign(a, y);
+}
+
 // num / d for one divisor and many numerators, bit for bit what the compiler's division sequence gives for numerators of
 // ordinary size: that sequence scales its operands only at the ends of the exponent range (v_div_scale_f64), and
 // otherwise is a reciprocal refined twice -- which depends on the divisor alone and is formed once here --, a product,
@@ -55,13 +94,19 @@ __device__ __forceinline__ DivBy make_div_by(double d) {
   e = __builtin_fma(-d, r, 1.0);
   r = __builtin_fma(r, e, r);
   D.r = r;
-  D.usable = d >= 0x1p-100 && d <= 0x1p100;
+  const double ad = __builtin_fabs(d);
+  D.usable = ad >= 0x1p-100 && ad <= 0x1p100;
   return D;
 }
 __device__ __forceinline__ double div_by(double num, const DivBy& D) {
   const double q0 = num * D.r;
   const double rem = __builtin_fma(-D.d, q0, num);
   return __builtin_fma(rem, D.r, q0);
+}
+
+// ... and the compiler's division where the divisor is not of ordinary size (zero, infinite, NaN included)
+__device__ __forceinline__ double div_by_checked(double num, const DivBy& D) {
+  return D.usable ? div_by(num, D) : num / D.d;
 }
 
 }  // namespace mcl

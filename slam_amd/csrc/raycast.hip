@@ -44,7 +44,7 @@
 
 #include "device_rng.h"
 #include "mclhip_internal.h"
-#include "exp_nonpos.h"
+#include "libm_bits.h"
 
 namespace mcl {
 

@@ -4,7 +4,7 @@
 //
 // Compiled with -ffp-contract=off.
 #include "mclhip_internal.h"
-#include "exp_nonpos.h"
+#include "libm_bits.h"
 
 namespace mcl {
 
