@@ -13,6 +13,13 @@ __device__ __forceinline__ double fma3(double a, double b, double c) {
   asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
+// ... with the addend in scalar registers: a constant is then two scalar moves where it is used (they issue beside the
+// vector instructions) and takes no vector registers at all
+__device__ __forceinline__ double fma3s(double a, double b, double c) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+  return d;
+}
 
 // exp(x) for x <= 0 (or NaN), bit for bit what the device library's exp returns there: the same reduction
 // (n = rint(x log2 e), r = x - n ln2 in two parts), the same degree-11 polynomial, ldexp, zero below -1075 -- without
@@ -22,15 +29,15 @@ __device__ __forceinline__ double exp_nonpos(double x) {
   const double n = __builtin_rint(x * __longlong_as_double(0x3ff71547652b82fell));
   double r = __builtin_fma(n, __longlong_as_double((long long)0xbfe62e42fefa39efull), x);
   r = __builtin_fma(n, __longlong_as_double((long long)0xbc7abc9e3b39803full), r);
-  double p = fma3(r, __longlong_as_double(0x3e5ade156a5dcb37ll), __longlong_as_double(0x3e928af3fca7ab0cll));
-  p = fma3(r, p, __longlong_as_double(0x3ec71dee623fde64ll));
-  p = fma3(r, p, __longlong_as_double(0x3efa01997c89e6b0ll));
-  p = fma3(r, p, __longlong_as_double(0x3f2a01a014761f6ell));
-  p = fma3(r, p, __longlong_as_double(0x3f56c16c1852b7b0ll));
-  p = fma3(r, p, __longlong_as_double(0x3f81111111122322ll));
-  p = fma3(r, p, __longlong_as_double(0x3fa55555555502a1ll));
-  p = fma3(r, p, __longlong_as_double(0x3fc5555555555511ll));
-  p = fma3(r, p, __longlong_as_double(0x3fe000000000000bll));
+  double p = fma3s(r, __longlong_as_double(0x3e5ade156a5dcb37ll), __longlong_as_double(0x3e928af3fca7ab0cll));
+  p = fma3s(r, p, __longlong_as_double(0x3ec71dee623fde64ll));
+  p = fma3s(r, p, __longlong_as_double(0x3efa01997c89e6b0ll));
+  p = fma3s(r, p, __longlong_as_double(0x3f2a01a014761f6ell));
+  p = fma3s(r, p, __longlong_as_double(0x3f56c16c1852b7b0ll));
+  p = fma3s(r, p, __longlong_as_double(0x3f81111111122322ll));
+  p = fma3s(r, p, __longlong_as_double(0x3fa55555555502a1ll));
+  p = fma3s(r, p, __longlong_as_double(0x3fc5555555555511ll));
+  p = fma3s(r, p, __longlong_as_double(0x3fe000000000000bll));
   p = __builtin_fma(r, p, 1.0);
   p = __builtin_fma(r, p, 1.0);
   const double v = ldexp(p, (int)n);
@@ -45,25 +52,25 @@ __device__ __forceinline__ double atan2_bits(double y, double x) {
   const double v = __builtin_fmax(ax, ay), u = __builtin_fmin(ax, ay);
   const double q = u / v;
   const double s = q * q;
-  double p = fma3(s, __longlong_as_double(0x3eeba404b5e68a13ll), __longlong_as_double((long long)0xbf23e260bd3237f4ull));
-  p = fma3(s, p, __longlong_as_double(0x3f4b2bb069efb384ll));
-  p = fma3(s, p, __longlong_as_double((long long)0xbf67952daf56de9bull));
-  p = fma3(s, p, __longlong_as_double(0x3f7d6d43a595c56fll));
-  p = fma3(s, p, __longlong_as_double((long long)0xbf8c6ea4a57d9582ull));
-  p = fma3(s, p, __longlong_as_double(0x3f967e295f08b19fll));
-  p = fma3(s, p, __longlong_as_double((long long)0xbf9e9ae6fc27006aull));
-  p = fma3(s, p, __longlong_as_double(0x3fa2c15b5711927all));
-  p = fma3(s, p, __longlong_as_double((long long)0xbfa59976e82d3ff0ull));
-  p = fma3(s, p, __longlong_as_double(0x3fa82d5d6ef28734ll));
-  p = fma3(s, p, __longlong_as_double((long long)0xbfaae5ce6a214619ull));
-  p = fma3(s, p, __longlong_as_double(0x3fae1bb48427b883ll));
-  p = fma3(s, p, __longlong_as_double((long long)0xbfb110e48b207f05ull));
-  p = fma3(s, p, __longlong_as_double(0x3fb3b13657b87036ll));
-  p = fma3(s, p, __longlong_as_double((long long)0xbfb745d119378e4full));
-  p = fma3(s, p, __longlong_as_double(0x3fbc71c717e1913cll));
-  p = fma3(s, p, __longlong_as_double((long long)0xbfc2492492376b7dull));
-  p = fma3(s, p, __longlong_as_double(0x3fc99999999952ccll));
-  p = fma3(s, p, __longlong_as_double((long long)0xbfd5555555555523ull));
+  double p = fma3s(s, __longlong_as_double(0x3eeba404b5e68a13ll), __longlong_as_double((long long)0xbf23e260bd3237f4ull));
+  p = fma3s(s, p, __longlong_as_double(0x3f4b2bb069efb384ll));
+  p = fma3s(s, p, __longlong_as_double((long long)0xbf67952daf56de9bull));
+  p = fma3s(s, p, __longlong_as_double(0x3f7d6d43a595c56fll));
+  p = fma3s(s, p, __longlong_as_double((long long)0xbf8c6ea4a57d9582ull));
+  p = fma3s(s, p, __longlong_as_double(0x3f967e295f08b19fll));
+  p = fma3s(s, p, __longlong_as_double((long long)0xbf9e9ae6fc27006aull));
+  p = fma3s(s, p, __longlong_as_double(0x3fa2c15b5711927all));
+  p = fma3s(s, p, __longlong_as_double((long long)0xbfa59976e82d3ff0ull));
+  p = fma3s(s, p, __longlong_as_double(0x3fa82d5d6ef28734ll));
+  p = fma3s(s, p, __longlong_as_double((long long)0xbfaae5ce6a214619ull));
+  p = fma3s(s, p, __longlong_as_double(0x3fae1bb48427b883ll));
+  p = fma3s(s, p, __longlong_as_double((long long)0xbfb110e48b207f05ull));
+  p = fma3s(s, p, __longlong_as_double(0x3fb3b13657b87036ll));
+  p = fma3s(s, p, __longlong_as_double((long long)0xbfb745d119378e4full));
+  p = fma3s(s, p, __longlong_as_double(0x3fbc71c717e1913cll));
+  p = fma3s(s, p, __longlong_as_double((long long)0xbfc2492492376b7dull));
+  p = fma3s(s, p, __longlong_as_double(0x3fc99999999952ccll));
+  p = fma3s(s, p, __longlong_as_double((long long)0xbfd5555555555523ull));
   const double t = s * p;
   double a = __builtin_fma(q, t, q);
   const double half_pi = __longlong_as_double(0x3ff921fb54442d18ll), pi = __longlong_as_double(0x400921fb54442d18ll);
