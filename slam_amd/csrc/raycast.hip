@@ -189,7 +189,7 @@ __device__ inline float bearing_turns_f32(float dy, float dx) {
 // Kept out of line: it runs for a few cells in a thousand, and inlined its two dozen polynomial
 // constants would sit in registers of the hot loop.
 __device__ __attribute__((noinline)) double exact_bearing(double dy, double dx) {
-  double a = atan2(dy, dx);
+  double a = atan2_bits(dy, dx);   // (the device library's atan2, bit for bit)
   if (a < 0.0) a += kTwoPi;
   return a;
 }
