@@ -1227,7 +1227,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
       }
       for (int cc = lane; cc < B; cc += 64) {
         const double z = use_iv ? etac[cc] : sqrt(__longlong_as_double((long long)rmin[G + cc]));   // robot.py:269
-        etac[cc] = 1.0 / (1.0 - exp_nonpos(-P.lambda * z));
+        etac[cc] = 1.0 / (1.0 - exp_nonpos<true>(-P.lambda * z));
         rmin[zoff + cc] = (unsigned long long)__double_as_longlong(z);
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1245,7 +1245,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
           const bool in_range = (0.0 <= xm) && (xm <= P.z_max);
           const double d = xm - z;
           const double num = -0.5 * (d * d);
-          double e_hit = exp_nonpos(kFastDiv ? div_by(num, by_sigma2) : num / P.sigma2);
+          double e_hit = exp_nonpos<true>(kFastDiv ? div_by(num, by_sigma2) : num / P.sigma2);
           asm volatile("" : "+v"(e_hit));   // (taken here: not moved under a branch on the range test, where the second entry's chain could not join it)
           const double p_hit = in_range ? P.c_hit * e_hit : 0.0;
           const double p_short = ((0.0 <= xm) && (xm <= z)) ? eta * P.lambda * el : 0.0;
@@ -1261,7 +1261,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
           double z = __longlong_as_double((long long)rmin[zoff + cc]);
           double eta = etac[cc];
           const double zo = sqrt(__longlong_as_double((long long)emin[k]));
-          if (zo < z) { z = zo; eta = 1.0 / (1.0 - exp_nonpos(-P.lambda * z)); }
+          if (zo < z) { z = zo; eta = 1.0 / (1.0 - exp_nonpos<true>(-P.lambda * z)); }
           emin[k] = (unsigned long long)__double_as_longlong(entry_px((int)(ck & 0x3ffu), z, eta));
         };
         STAMP(4);   // (histogram filter: class ranges and normalisers)

@@ -13,8 +13,8 @@ __global__ void check(uint64_t n, double lo, double step, unsigned long long* ba
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double x = lo + (double)i * step;
-  const double a = mcl::exp_nonpos(x), b = exp(x);
-  if (__double_as_longlong(a) != __double_as_longlong(b)) {
+  const double a = mcl::exp_nonpos(x), a2 = mcl::exp_nonpos<true>(x), b = exp(x);
+  if (__double_as_longlong(a) != __double_as_longlong(b) || __double_as_longlong(a2) != __double_as_longlong(b)) {
     if (atomicAdd(bad, 1ull) == 0ull) *first_bad = x;
   }
 }
@@ -23,8 +23,8 @@ __global__ void check_list(const double* xs, int n, unsigned long long* bad, dou
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double x = xs[i];
-  const double a = mcl::exp_nonpos(x), b = exp(x);
-  const bool same = __double_as_longlong(a) == __double_as_longlong(b) || (a != a && b != b);
+  const double a = mcl::exp_nonpos(x), a2 = mcl::exp_nonpos<true>(x), b = exp(x);
+  const bool same = (__double_as_longlong(a) == __double_as_longlong(b) && __double_as_longlong(a2) == __double_as_longlong(b)) || (a != a && a2 != a2 && b != b);
   if (!same) {
     if (atomicAdd(bad, 1ull) == 0ull) *first_bad = x;
   }
