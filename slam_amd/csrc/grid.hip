@@ -194,19 +194,32 @@ __global__ __launch_bounds__(512) void chunk_sum_f32_kernel(const float* __restr
   }
 }
 
-__global__ void total_sum_f32_kernel(const float* __restrict__ chunk_sums, int64_t nchunks, float* __restrict__ total) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  float t = chunk_sums[0];
-  int64_t i = 1;
-  for (; i + 16 <= nchunks; i += 16) {   // loads issued together, additions strictly left to right
-    float v[16];
+// the chunk sums added strictly left to right by one lane -- out of LDS, where the whole block has staged them (read
+// from memory sixteen at a time the chain waited for a memory round trip per batch: 0.79 ms for the 36864 chunks of a
+// 2048 x 2048 x 72 belief)
+constexpr int kTotalStage = 8192;
+__global__ __launch_bounds__(1024) void total_sum_f32_kernel(const float* __restrict__ chunk_sums, int64_t nchunks, float* __restrict__ total) {
+  __shared__ __align__(16) float s_v[kTotalStage];
+  float t = 0.0f;
+  for (int64_t base = 0; base < nchunks; base += kTotalStage) {
+    const int cnt = (int)((nchunks - base) < kTotalStage ? (nchunks - base) : kTotalStage);
+    __syncthreads();
+    for (int k = threadIdx.x; k < cnt; k += blockDim.x) s_v[k] = chunk_sums[base + k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int i = 0;
+      if (base == 0) { t = s_v[0]; i = 1; }
+      for (; i + 16 <= cnt; i += 16) {   // reads issued together, additions strictly left to right
+        float v[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = chunk_sums[i + j];
+        for (int j = 0; j < 16; ++j) v[j] = s_v[i + j];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) t = t + v[j];
+        for (int j = 0; j < 16; ++j) t = t + v[j];
+      }
+      for (; i < cnt; ++i) t = t + s_v[i];
+    }
   }
-  for (; i < nchunks; ++i) t = t + chunk_sums[i];
-  total[0] = t;
+  if (threadIdx.x == 0) total[0] = t;
 }
 
 __global__ void divide_f32_kernel(float* __restrict__ w, int64_t n, const float* __restrict__ total) {
@@ -457,7 +470,7 @@ int mclhip_grid_update(mclhip_ctx* c, const double* z_meas, float* sum_out) {
   G_TRY(launch_grid_update(c, c->gl_x, c->gl_y, c->gl_th, c->gl_cell, c->gl_nfree, D, B0, c->gl_pk_pred, c->gl_pk));
   const int64_t nchunks = (n + kSumChunk - 1) / kSumChunk;
   hipLaunchKernelGGL(chunk_sum_f32_kernel, dim3((unsigned)nchunks), dim3(512), 0, c->stream, c->gl_pk, n, c->gl_part);
-  hipLaunchKernelGGL(total_sum_f32_kernel, dim3(1), dim3(64), 0, c->stream, c->gl_part, nchunks, c->gl_part + nchunks);
+  hipLaunchKernelGGL(total_sum_f32_kernel, dim3(1), dim3(1024), 0, c->stream, c->gl_part, nchunks, c->gl_part + nchunks);
   hipLaunchKernelGGL(divide_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->gl_pk, n,
                      c->gl_part + nchunks);
   tm.stop();
