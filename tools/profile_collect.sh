@@ -7,7 +7,7 @@ src=gpurun_out/prof_$tag
 cd "$(dirname "$0")/.."
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -S --cuda-device-only"
 /opt/rocm/bin/hipcc $FLAGS slam_amd/csrc/raycast.hip -o /tmp/raycast_$tag.s 2>/dev/null
-RAYSRC="slam_amd/csrc/raycast.hip slam_amd/csrc/mclhip_internal.h slam_amd/csrc/device_rng.h"
+RAYSRC="slam_amd/csrc/raycast.hip slam_amd/csrc/mclhip_internal.h slam_amd/csrc/device_rng.h slam_amd/csrc/libm_bits.h"
 cells_of() { grep -ho "cells_in_range [0-9.]*" $1/pmc_f64.log 2>/dev/null | head -1 | cut -d' ' -f2; }
 if [ -d $src/mcl ]; then
   cp $src/mcl_trace/bench_kernel_stats.csv profiles/${tag}_bench_kernel_stats.csv
