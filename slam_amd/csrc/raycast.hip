@@ -61,8 +61,11 @@ constexpr int kCapSpan = 16;
 constexpr int cap_buckets(int cap) { int n = 1; while (n < 2 * cap) n <<= 1; return n; }
 constexpr int kEdgeQueue = 32;        // cells on a sector edge that a particle can park (interval path); more: the particle is done entry by entry
 constexpr int kEdgeQueueWide = 64;    // ... in the interval-only kernel, whose queue also takes the unused part of the ring (see edgeq)
+// histogram filter: (heading, beam) entries a lane takes per round of the mixtures, in straight-line code so that their
+// float64 chains overlap.  936 entries are five rounds of 192 (2: eight rounds of 128; 4: four of 256): measured at
+// 2048 x 2048 x 72, 24.3 ms with two, 23.65 with three, 23.7 with four.
 #ifndef MCL_GRID_WAYS
-#define MCL_GRID_WAYS 2
+#define MCL_GRID_WAYS 3
 #endif
 constexpr int kSubLists = 64;         // the list of left-over particles is kept as this many lists with a counter each (blocks b, b + 64, ... share one)
 constexpr int kFiled = 16;            // particles an interval-only wave notes before it appends them to the list in one go
@@ -1217,9 +1220,23 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
       // (with sector intervals a class's squared range is the smaller of its intervals', and its root goes where the
       // intervals stood: every class reads first -- the roots wait in the other array meanwhile)
       const int zoff = use_iv ? 0 : G;
+      if (use_iv && B <= 128) {
+        // up to two classes per lane, both in straight-line code (their chains of a root, an exponential and a division
+        // overlap): the ranges first -- every class reads the interval minima before any class's range is written over
+        // them --, then normalisers and stores
+        const int ca = lane < B ? lane : B - 1, cb = lane + 64 < B ? lane + 64 : B - 1;
+        // (the class's own minimum: parked cells that its sector holds inside, see above)
+        const unsigned long long held_a = reinterpret_cast<const unsigned long long*>(etac)[ca], spans_a = beam_r2bits(ca);
+        const unsigned long long held_b = reinterpret_cast<const unsigned long long*>(etac)[cb], spans_b = beam_r2bits(cb);
+        const double za = sqrt(__longlong_as_double((long long)(held_a < spans_a ? held_a : spans_a)));   // robot.py:269
+        const double zb = sqrt(__longlong_as_double((long long)(held_b < spans_b ? held_b : spans_b)));
+        const double na = 1.0 / (1.0 - exp_nonpos<true>(-P.lambda * za)), nb = 1.0 / (1.0 - exp_nonpos<true>(-P.lambda * zb));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane < B) { etac[ca] = na; rmin[zoff + ca] = (unsigned long long)__double_as_longlong(za); }
+        if (lane + 64 < B) { etac[cb] = nb; rmin[zoff + cb] = (unsigned long long)__double_as_longlong(zb); }
+      } else {
       if (use_iv) {
         for (int cc = lane; cc < B; cc += 64) {
-          // (the class's own minimum: parked cells that its sector holds inside, see above)
           const unsigned long long held = reinterpret_cast<const unsigned long long*>(etac)[cc], spans = beam_r2bits(cc);
           etac[cc] = sqrt(__longlong_as_double((long long)(held < spans ? held : spans)));   // robot.py:269
         }
@@ -1229,6 +1246,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
         const double z = use_iv ? etac[cc] : sqrt(__longlong_as_double((long long)rmin[G + cc]));   // robot.py:269
         etac[cc] = 1.0 / (1.0 - exp_nonpos<true>(-P.lambda * z));
         rmin[zoff + cc] = (unsigned long long)__double_as_longlong(z);
+      }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       // p(z_meas | z_pred) of one entry (range_sensor.py:95-112 called from robot.py:297)
@@ -1266,9 +1284,10 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
         };
         STAMP(4);   // (histogram filter: class ranges and normalisers)
         int waiting = 0;
-        // two entries per lane and round, in straight-line code (an entry beyond the table computes the last one's value and
-        // drops it, one that waits for its own range computes its class's and drops it): the two chains of float64
-        // arithmetic -- an exponential and a division each -- overlap, which four waves per SIMD alone do not hide
+        // several entries per lane and round (MCL_GRID_WAYS), in straight-line code (an entry beyond the table computes the
+        // last one's value and drops it, one that waits for its own range computes its class's and drops it): their
+        // chains of float64 arithmetic -- an exponential and a division each -- overlap, which four waves per SIMD
+        // alone do not hide
         constexpr int kWays = MCL_GRID_WAYS;
         for (int k0 = 0; k0 < NE; k0 += 64 * kWays) {
           int kk[kWays];
