@@ -324,7 +324,10 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
   unsigned int* s_cls = reinterpret_cast<unsigned int*>(s_lut + (IVONLY ? 0 : ((NB + B + 1) & ~1) - B));   // [NE] class << 20 | heading << 10 | beam of entry e (GRID), 4-byte aligned
   // GRID: what the entry-by-entry test at a sector edge reads -- the entries of every class and the two terms of an entry's own angle
   double* s_ang = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(s_cls + NE) + 7) & ~(uintptr_t)7);   // [B0] beam angles, [D] heading angles (radians)
-  unsigned short* s_member = reinterpret_cast<unsigned short*>(s_ang + (GRID ? P.g_B0 + P.g_D : 0));   // [NE] entries by class
+  // (behind the angles, per beam of the measurement: p_max * w_max and p_rand * w_rand of the mixture, which depend on
+  // the measured range alone -- two reads per entry instead of eight instructions)
+  double* s_tail = s_ang + (GRID ? P.g_B0 + P.g_D : 0);         // [2 B0]
+  unsigned short* s_member = reinterpret_cast<unsigned short*>(s_tail + (GRID ? 2 * P.g_B0 : 0));   // [NE] entries by class
   unsigned short* s_first = s_member + NE;                                                     // [B + 1] start of every class in s_member
   // the interval tables stand where the class tables would (GRID: behind them)
   float* s_ivedge = GRID ? reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(s_first + B + 1) + 3) & ~(uintptr_t)3)
@@ -399,6 +402,13 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
     for (int k = threadIdx.x; k < NE; k += blockDim.x) { s_cls[k] = P.g_cls[k]; s_member[k] = P.g_member[k]; }
     for (int k = threadIdx.x; k <= B; k += blockDim.x) s_first[k] = P.g_cls_first[k];
     for (int k = threadIdx.x; k < P.g_B0 + P.g_D; k += blockDim.x) s_ang[k] = P.g_ar[k];   // one array: beams, then headings
+    for (int k = threadIdx.x; k < P.g_B0; k += blockDim.x) {
+      const double xm = P.zt[k];                                  // range_sensor.py:55-67 for the measured range
+      const double p_max = (fabs(xm - P.z_max) < 1e-6) ? 1.0 : 0.0;
+      const double p_rand = ((0.0 <= xm) && (xm <= P.z_max)) ? P.p_rand : 0.0;
+      s_tail[k] = p_max * P.w_max;
+      s_tail[P.g_B0 + k] = p_rand * P.w_rand;
+    }
   }
   if (!IVONLY && !(LISTED && FAST)) {
     for (int k = threadIdx.x; k < NXP; k += blockDim.x) s_relx[k] = (k < P.G + B) ? P.relx[k] : 1.0e30f;  // padding: beyond any window
@@ -1267,9 +1277,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
           asm volatile("" : "+v"(e_hit));   // (taken here: not moved under a branch on the range test, where the second entry's chain could not join it)
           const double p_hit = in_range ? P.c_hit * e_hit : 0.0;
           const double p_short = ((0.0 <= xm) && (xm <= z)) ? eta * P.lambda * el : 0.0;
-          const double p_max = (fabs(xm - P.z_max) < 1e-6) ? 1.0 : 0.0;
-          const double p_rand = in_range ? P.p_rand : 0.0;
-          return p_hit * P.w_hit + p_short * P.w_short + p_max * P.w_max + p_rand * P.w_rand;
+          return p_hit * P.w_hit + p_short * P.w_short + s_tail[kb] + s_tail[P.g_B0 + kb];   // (+ p_max * w_max + p_rand * w_rand)
         };
         // entries whose own minimum may undercut their class wait in the ring and are done together, so the
         // common case stays free of the root / exponential / division they need
@@ -1530,7 +1538,7 @@ static size_t ray_lds_bytes(int B, int G, int NB, bool aux, int waves = kWavesPe
     s += (size_t)(iv_NE + 1) * sizeof(float) + ((size_t)B + iv_NB + 2) * sizeof(unsigned short) + (size_t)iv_NE * sizeof(unsigned int) + 8;
   if (NE) {
     s += (size_t)NE * sizeof(unsigned int) + 8;                            // class / heading / beam of every entry (+ alignment of what follows)
-    s += (size_t)(B0 + NE / B0) * sizeof(double);                          // beam and heading angles
+    s += (size_t)(3 * B0 + NE / B0) * sizeof(double);                      // beam and heading angles, the mixture's per-beam terms
     s += ((size_t)NE + B + 2) * sizeof(unsigned short);                    // entries by class, class starts
   }
   return (s + 15) & ~(size_t)15;
