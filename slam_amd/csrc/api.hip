@@ -323,7 +323,7 @@ static int enqueue_sample(mclhip_ctx* c, double v, double omega, double dt, cons
   const int a = c->cur;
   // log-weights from the float32 mixture: the query may run as the interval-only kernel, which reads the motion
   // kernel's records (launch_raycast decides; records it does not use cost 32 bytes per particle of writes)
-  if (!want_product && !d_range_noise && !(rn_sigma > 0.0) && c->zmeas_ok) make_query_prep(c, mp.qp);
+  if (!want_product && !d_range_noise && c->zmeas_ok) make_query_prep(c, mp.qp);
   // (the measurement's table and the left-over counts are the query's business: one more block of the motion kernel
   // sees to both, see StepPrep)
   if (!c->zsrc || c->zsrc_slot < 0) return fail(c, MCLHIP_E_STATE, "no measurement at hand");
@@ -587,6 +587,27 @@ int mcl::set_sensor_table(mclhip_ctx* c, const double* tab_rad, int B, double z_
       for (double v : all)
         if (edge.empty() || v - edge.back() > 1e-9) edge.push_back(v);
       if (edge.size() > 1 && two_pi - edge.back() <= 1e-9) edge.pop_back();        // the same edge as 0 from the other side
+      // Edges that all fall on multiples of one width (the reference's own beams: every 15 degrees, sectors of +-5,
+      // so every edge is a multiple of 5 degrees): the circle is cut into that many equal intervals instead, some of
+      // which no sector spans -- a bearing's interval is then arithmetic, not a search (the kernels' "even" layouts)
+      if (edge.size() >= 2) {
+        double gmin = two_pi - edge.back() + edge.front();
+        for (size_t m = 0; m + 1 < edge.size(); ++m) gmin = std::min(gmin, edge[m + 1] - edge[m]);
+        const long nn = gmin > 1e-4 ? std::lround(two_pi / gmin) : 0;
+        if (nn >= 2 && nn <= 384 && (size_t)nn > edge.size()) {
+          bool lattice = true;
+          for (double v : edge) {
+            const double q = v * (double)nn / two_pi;
+            if (std::fabs(q - std::round(q)) * two_pi / (double)nn > 1e-9) lattice = false;
+          }
+          if (lattice) {
+            std::vector<double> even((size_t)nn);
+            for (long m = 0; m < nn; ++m) even[(size_t)m] = two_pi * (double)m / (double)nn;
+            for (double v : edge) even[(size_t)(std::lround(v * (double)nn / two_pi) % nn)] = v;   // (the sectors' own edges as they are)
+            edge.swap(even);
+          }
+        }
+      }
       const int NE = (int)edge.size();
       auto index_of = [&](double v) {            // the merged edge nearest to v on the circle
         int best = 0; double bd = 1e9;
@@ -962,7 +983,13 @@ int mclhip_sample_augmented_device(mclhip_ctx* c, double v, double omega, double
   if (!(range_sigma > 0.0)) return fail(c, MCLHIP_E_ARG, "range_sigma must be positive");
   MCL_TRY(upload_zmeas(c, z_meas));
   // integers of the motion sampler uniform on [-1000, 1000): np.random.randint(-1000, 1000, 12) (mc_localization2.py:23)
-  MCL_TRY(enqueue_sample(c, v, omega, dt, alpha, 2, seed, c->spans, true, nullptr, range_sigma, 2000));
+  // float32 state: log-weights from the float32 mixture (the interval-only sector query with the noise drawn in its
+  // mixture, three times as fast as the general kernel), the raw weights of mc_localization2.py:235-240 as their
+  // exponentials -- the noise is the device's own, so what is kept is the distribution, not a sequence of roundings.
+  // float64 state: the product itself, factor by factor.
+  const bool from_log = c->dtype == MCLHIP_F32;
+  MCL_TRY(enqueue_sample(c, v, omega, dt, alpha, 2, seed, c->spans, !from_log, nullptr, range_sigma, 2000));
+  if (from_log) MCL_TRY(launch_exp_weights(c));
   MCL_TRY(launch_mean_weight(c));
   MCL_HIP(c, hipStreamSynchronize(c->stream));
   span_collect(c, c->spans);

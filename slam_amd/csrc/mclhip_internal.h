@@ -390,6 +390,7 @@ int ray_arith_span(const mclhip_ctx* c);
 // ... and that kernel also serves the headings outside the circular range
 bool ray_serves_every_heading(const mclhip_ctx* c);
 int launch_mean_weight(mclhip_ctx* c);
+int launch_exp_weights(mclhip_ctx* c);   // w = exp(logw) for the live set
 int launch_sequential_total(mclhip_ctx* c);   // c->cdf_exact = strictly sequential running sum of the live weights
 void fs_release(mclhip_ctx* c);
 int launch_inject(mclhip_ctx* c, const int64_t* d_rows, const double* d_poses, int64_t n_inj, int which_buffer,

@@ -1376,6 +1376,30 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
       auto beam_factor = [&](int k) {
         const unsigned long long rb = beam_r2bits(k);
         const double r2 = __longlong_as_double((long long)rb);
+        if constexpr (RNOISE) {
+          // augmented MCL with device-drawn range noise (mc_localization2.py:166-173): r + sigma n on the predicted
+          // range -- min(z_max, z_max + sigma n) on a map without obstacles --, n from one counter block per
+          // (particle, beam in sorted order).  The noisy range can leave [0, z_max], so every indicator of
+          // range_sensor.py:31-67 is taken on it; the cancellation-free difference of the noiseless path has nothing to
+          // offer here (the noise is of the size of sigma_hit), the terms are plain float32.
+          const uint64_t gp = (uint64_t)(P.rn_index0 + p);
+          uint32_t ctr[4] = {(uint32_t)gp, (uint32_t)(gp >> 32), (uint32_t)k, 0x524fu};
+          philox4x32(ctr, (uint32_t)P.rn_seed, (uint32_t)(P.rn_seed >> 32));
+          double n0, n1;
+          box_muller_f32(ctr[0], ctr[1], &n0, &n1);
+          const float term = (float)n0 * (float)P.rn_sigma;
+          const float zmaxf = (float)P.z_max;
+          const float2 zf = reinterpret_cast<const float2*>(s_el)[k];   // z*, eta * lambda * w_short
+          const float zn = P.no_obstacles ? fminf(zmaxf, zmaxf + term) : __builtin_amdgcn_sqrtf((float)r2) + term;
+          const bool in_range = (0.0f <= zn) && (zn <= zmaxf);
+          const float d = zn - zf.x;
+          const float e_hit = __builtin_amdgcn_exp2f((d * d) * k_hit);
+          const float e_short = __builtin_amdgcn_exp2f(zn * k_short);
+          float small = in_range ? prw : 0.0f;
+          small = small + ((0.0f <= zn && zn <= zf.x) ? e_short * zf.y : 0.0f);
+          small = small + (fabsf(zn - zmaxf) < 1e-6f ? wmax : 0.0f);
+          return (in_range ? (double)e_hit * chw : 0.0) + (double)small;
+        }
         const float num = (float)(r2 - s_zt[k]);                      // z^2 - z*^2, cancellation exact in float64
         const float2 zf = reinterpret_cast<const float2*>(s_el)[k];   // z*, eta * lambda * w_short
         const float z0 = __builtin_amdgcn_sqrtf((float)r2);
@@ -1628,7 +1652,8 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
   const bool device_noise = rn_sigma > 0.0;
   const bool stage = ranges_out != nullptr;
   // log-weights only, float32 state, no range noise, measured ranges finite and >= 0: the float32 mixture
-  const bool fast = !stage && !device_noise && dtype == MCLHIP_F32 && !product && !range_noise && c->zmeas_ok && MCL_FAST_LIKELIHOOD;
+  // (device-drawn range noise as well, where the query runs as the two launches over a fixed layout: decided below)
+  bool fast = !stage && dtype == MCLHIP_F32 && !product && !range_noise && c->zmeas_ok && MCL_FAST_LIKELIHOOD;
   if (stage || !MCL_FAST_INTERVALS) { P.iv_NE = 0; P.iv_cmax = 0; }
   // The float32-mixture path with sector intervals runs as two launches: the interval-only kernel, which files the
   // particles it does not serve (headings outside the interval path's range: 5 % of a uniform cloud), and the general
@@ -1642,7 +1667,7 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
       left_a += reinterpret_cast<volatile uint32_t*>(c->redo_hint)[k];
       left_b += reinterpret_cast<volatile uint32_t*>(c->redo_hint)[kSubLists + k];
     }
-  const bool every = split && ray_serves_every_heading(c) && c->redo_list2 != nullptr &&
+  const bool every = split && !device_noise && ray_serves_every_heading(c) && c->redo_list2 != nullptr &&
                      (c->every_heading == 1 || (c->every_heading < 0 && left_a * 16 > (uint64_t)n && left_a * 2 < (uint64_t)n));
   if (split && c->split_mode < 0 && c->redo_hint) {
     const uint64_t left = every ? left_b : left_a;
@@ -1658,6 +1683,9 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
     auto fits = [&](int cc) { return P.B <= cc && P.iv_NE <= cc && P.iv_NB <= cap_buckets(cc); };
     if (fits(192)) cap = 192;
     else if (fits(384) && 2 * kWavesPerBlock <= 16) { cap = 384; wpb = 2 * kWavesPerBlock; }
+  }
+  if (fast && device_noise && !(split && cap != 0)) {   // no fixed layout for this table: the general kernel draws the noise
+    fast = false; split = false; cap = 0; wpb = kWavesPerBlock;
   }
   auto lds_of = [&](int w) { return ray_lds_bytes(P.B, P.G, P.NB, stage || product, w, 0, 0, P.iv_NE, P.iv_NB, P.iv_cmax, split, cap); };
   if (fast && cap == 0 && 2 * kWavesPerBlock <= 16) {
@@ -1690,7 +1718,7 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
   if (stage) {
     if (dtype != MCLHIP_F64) return fail(c, MCLHIP_E_ARG, "stage query takes float64 poses");
     MCL_RAY(double, true, false);
-  } else if (device_noise) {
+  } else if (device_noise && !fast) {
     if (dtype == MCLHIP_F32) {
       if (product) MCL_RAY_N(float, false, true, true); else MCL_RAY_N(float, false, false, true);
     } else {
@@ -1710,7 +1738,11 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
       timing_begin(c, 0);
       const bool even = c->iv_uniform;                                       // equally wide intervals
       const int arith = ray_arith_span(c);                                   // ... as many per sector, sectors start at k * stride: the UNIF > 0 variants
-      if (cap == 192 && arith == 5) MCL_RAY_U(float, false, false, false, true, kWavesPerBlock, true, false, 192, 5);
+      if (device_noise && cap == 192 && even) MCL_RAY_U(float, false, false, true, true, kWavesPerBlock, true, false, 192, -1);
+      else if (device_noise && cap == 192) MCL_RAY_U(float, false, false, true, true, kWavesPerBlock, true, false, 192, 0);
+      else if (device_noise && even) MCL_RAY_U(float, false, false, true, true, 2 * kWavesPerBlock, true, false, 384, -1);
+      else if (device_noise) MCL_RAY_U(float, false, false, true, true, 2 * kWavesPerBlock, true, false, 384, 0);
+      else if (cap == 192 && arith == 5) MCL_RAY_U(float, false, false, false, true, kWavesPerBlock, true, false, 192, 5);
       else if (cap == 192 && even) MCL_RAY_U(float, false, false, false, true, kWavesPerBlock, true, false, 192, -1);
       else if (cap == 384 && arith == 10) MCL_RAY_U(float, false, false, false, true, 2 * kWavesPerBlock, true, false, 384, 10);
       else if (cap == 384 && even) MCL_RAY_U(float, false, false, false, true, 2 * kWavesPerBlock, true, false, 384, -1);
@@ -1759,7 +1791,8 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
       if (blocks_b > (every ? 512 : 3584)) blocks_b = every ? 512 : 3584;
       blocks_b = (blocks_b + kSubLists - 1) / kSubLists * kSubLists;      // the same number of blocks behind every list
       {
-        auto kern = raycast_kernel<float, false, false, false, kWavesPerBlock, false, true, false, true>;
+        auto kern = device_noise ? raycast_kernel<float, false, false, false, kWavesPerBlock, true, true, false, true>
+                                 : raycast_kernel<float, false, false, false, kWavesPerBlock, false, true, false, true>;
         if (lds_b > 48 * 1024)
           MCL_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks_b), block.x == 64u * kWavesPerBlock ? block : dim3(64 * kWavesPerBlock), lds_b, c->stream, P,

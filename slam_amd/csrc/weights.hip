@@ -1023,6 +1023,20 @@ __global__ void exp_shift_by_kernel(const double* __restrict__ logw, double* __r
   w[i] = (mx == -INFINITY) ? 0.0 : exp_nonpos(logw[i] - mx);
 }
 
+// raw weights from log-weights: w = exp(logw) (a particle off the free cells has -inf and gets 0)
+__global__ void exp_weights_kernel(const double* __restrict__ logw, double* __restrict__ w, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) w[i] = exp(logw[i]);
+}
+
+int launch_exp_weights(mclhip_ctx* c) {
+  const int64_t n = c->M;
+  if (n <= 0) return MCLHIP_OK;
+  hipLaunchKernelGGL(exp_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->logw, c->w[c->cur], n);
+  MCL_HIP(c, hipGetLastError());
+  return MCLHIP_OK;
+}
+
 int launch_shard_max_logw(mclhip_ctx* c, double* d_also) {
   const int np = 1024;
   hipLaunchKernelGGL(max_partial_kernel, dim3(np), dim3(256), 0, c->stream, c->logw, c->M, (double*)c->blk_a);

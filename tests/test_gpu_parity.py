@@ -342,6 +342,67 @@ def test_sector_intervals_against_the_oracle(beams, every, monkeypatch):
     ctx.close()
 
 
+def test_augmented_mcl_device_noise_in_the_float32_mixture():
+    """Float32 state: the device-drawn range noise of augmented MCL goes through the interval-only sector query (noise
+    drawn inside its float32 mixture, raw weights as exponentials of the log-weights).  Its noise is a stream of its
+    own, so what is compared with the float64 path -- the general kernel, factor by factor -- is the distribution: per
+    particle the two log-weights differ by noise alone, with no bias; on a map without obstacles the moments are
+    those numpy gives for log p over n ~ N(0, 1) (mc_localization2.py:166-173)."""
+    from slam_amd import workload as W
+    L = _lib()
+    sp = O.SensorParams()
+    angles = [0, 15, 30, 45, 60, 75, 90, 345, 330, 315, 300, 285, 270]           # mc_localization2.py's beam set
+    grid = W.synthetic_map(256, target_occupancy=0.25)       # dense: few beams read z_max, where half the noisy ranges are out of range
+    M = 1 << 17
+    X = W.uniform_particles(grid, M, seed=5).astype(np.float32).astype(np.float64)
+    got = {}
+    for dtype in (L.F32, L.F64):
+        ctx = L.Context(0, dtype)
+        ctx.set_map(grid, W.RES, W.RES)
+        _sensor(ctx, angles)
+        z_meas = ctx.raycast(np.array([5.0, 7.5, 0.4]), want_hits=False)[0][0]
+        ctx.set_particles(X)
+        w_avg = ctx.sample_augmented_device(0.0, 0.0, 0.1, ALPHA, z_meas, 777, 0.15)     # no motion
+        Xd, w, logw = ctx.get_particles(True, True, True)
+        assert np.array_equal(Xd, X)
+        assert np.isclose(w_avg, np.mean(w), rtol=1e-9)
+        fin = np.isfinite(logw)
+        assert np.allclose(w[fin], np.exp(logw[fin]), rtol=1e-6) and np.all(w[~fin] == 0.0)
+        got[dtype] = (logw, ctx.query_kernel_name())
+        ctx.close()
+    # the float32 state took the interval-only kernel with the noise in it (template argument 6), the float64 state the general one
+    # (... over equal intervals: the reference's beam set has every sector edge on a multiple of five degrees)
+    assert got[L.F32][1] == "raycast_kernel<float,false,false,false,4,true,true,true,false,192,-1>", got[L.F32][1]
+    a, b = got[L.F32][0], got[L.F64][0]
+    both = np.isfinite(a) & np.isfinite(b)
+    # (a noisy range beyond z_max or below zero has likelihood zero: which particles that hits is the noise's doing)
+    fa, fb = np.isfinite(a).mean(), np.isfinite(b).mean()
+    assert abs(fa - fb) < 6 * np.sqrt(2 * fb * (1 - fb) / M) and both.sum() > 0.2 * M, (fa, fb)
+    d = a[both] - b[both]
+    assert d.std() > 0.05                                                        # different noise ...
+    assert abs(d.mean()) < 6 * d.std() / np.sqrt(both.sum())                     # ... the same distribution
+    assert abs(a[both].std() / b[both].std() - 1) < 0.02
+    # without obstacles: min(z_max, z_max + 0.15 n) on every beam
+    rng = np.random.RandomState(2)
+    M2, B = 1 << 18, 4
+    free = np.full((100, 100), 255, np.uint8)
+    ctx = L.Context(0, L.F32)
+    ctx.set_map(free, O.RES_X, O.RES_Y)
+    _sensor(ctx, [0, 90, 180, 270])
+    X2 = np.stack([rng.uniform(1, 5, M2), rng.uniform(1, 5, M2), rng.uniform(0, 6, M2)], 1)
+    ctx.set_particles(X2)
+    z_meas = np.array([5.0, 4.9, 4.7, 3.0])
+    ctx.sample_augmented_device(0.0, 0.0, 0.1, ALPHA, z_meas, 4242, 0.15)
+    logw = ctx.get_particles(True, True, True)[2]
+    n = rng.randn(2_000_000, B)
+    zp = np.minimum(sp.z_max, sp.z_max + 0.15 * n)
+    want = np.log(O.beam_px(zp, z_meas[None, :], sp)).sum(1)
+    assert abs(logw.mean() - want.mean()) < 6 * want.std() / np.sqrt(M2)
+    assert abs(logw.std() / want.std() - 1) < 0.02
+    assert abs(np.corrcoef(logw[:-1], logw[1:])[0, 1]) < 5 / np.sqrt(M2)
+    ctx.close()
+
+
 def test_dropin_class_follows_reference_run():
     """The drop-in class driven like the reference's __main__ (mc_localization.py:303-331) under
     the same np.random seed: same initial cloud, same indices, same trajectory."""
