@@ -212,7 +212,10 @@ int mclhip_resample_augmented(mclhip_ctx* ctx, double r, const int64_t* inj_rows
  * injection draws (:266-283: one uniform per position, injected when <= p_random; pose uniform over
  * [0, extent_x) x [0, extent_y) on a cell of value 255, heading U[0, 2pi)) come from the counter-based
  * generator keyed by the global particle index and `seed`.  Same distributions as the reference, not numpy's
- * stream.  n_injected_out (nullable): number of injected positions. */
+ * stream.  n_injected_out (nullable): number of injected positions.
+ * With float32 state the noise is drawn inside the float32 beam mixture of the interval-only sector query and the raw
+ * weights are the exponentials of the log-weights (relative error about 1e-7, and a noise stream of its own); with
+ * float64 state the product is formed factor by factor as the reference does (mc_localization2.py:235-240). */
 int mclhip_sample_augmented_device(mclhip_ctx* ctx, double v, double omega, double dt, const double alpha[6],
                                    uint64_t seed, const double* z_meas, double range_sigma, double* w_avg_out);
 int mclhip_resample_augmented_device(mclhip_ctx* ctx, double r, double p_random, double extent_x, double extent_y,
