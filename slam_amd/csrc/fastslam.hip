@@ -199,10 +199,14 @@ __device__ inline Predicted predict_feature(const RawFeat& r, double x, double y
 // The out-of-line helpers below see plain values and this lane's record pointers only -- nothing they
 // would have to read again after a store -- and their constants stay out of the registers of the loops.
 
-// the likelihood of a pair that passed the gate (:308-309)
-__device__ __attribute__((noinline)) double gate_weight(double d2, double dq) {
-  const double eta = 1.0 / (2.0 * M_PI * sqrt(dq));
-  return eta * exp(-0.5 * d2);
+// the likelihood of a pair that passed the gate (:308-309): eta depends on the feature alone and is formed once per
+// feature, beside the reads of its candidates, not behind them; the exponential with the library's bits in fewer
+// instructions (a positive argument -- an innovation covariance that is not positive definite -- takes the library's)
+__device__ __attribute__((noinline)) double library_exp(double x) { return exp(x); }   // (out of line: its constants stay out of the loops' registers)
+__device__ __forceinline__ double gate_eta(double dq) { return 1.0 / (2.0 * M_PI * sqrt(dq)); }
+__device__ __forceinline__ double gate_weight(double d2, double eta) {
+  const double arg = -0.5 * d2;
+  return eta * (arg <= 0.0 ? exp_nonpos<true>(arg) : library_exp(arg));
 }
 
 // new feature (:318-347)
@@ -345,6 +349,7 @@ __global__ __launch_bounds__(128, FS_WAVES) void fs_associate_kernel(const FsPar
       if ((dx * dx + dy * dy) * 0.9999f > lim * lim) continue;
     }
     const Predicted f = predict_feature(raw, x, y, th, P.qt_r, P.qt_phi, nullptr);
+    const double eta_j = gate_eta(f.dq);
     const double lim0 = two_gate * (f.q11 * f.dq), lim1 = two_gate * (f.q00 * f.dq);
     const float lim0f = (float)lim0 * 1.0001f, lim1f = (float)lim1 * 1.0001f;      // NaN: nothing is out, the close test decides
     const float ffr = (float)f.fr, ffphi = (float)f.fphi;
@@ -402,7 +407,7 @@ __global__ __launch_bounds__(128, FS_WAVES) void fs_associate_kernel(const FsPar
             const double t1 = e0 * f.q01 + e1 * f.q11;
             const double d2 = t0 * e0 + t1 * e1;
             if (d2 <= P.gate2) {                          // :307
-              const double w = gate_weight(d2, f.dq);
+              const double w = gate_weight(d2, eta_j);
               if (bw[k] < w) wj[k] = w;                   // :311 (a NaN likelihood never wins)
             }
           }
