@@ -291,15 +291,20 @@ __global__ __launch_bounds__(256) void motion_kernel(T* __restrict__ xs, T* __re
     g_hat = mp.c3 * sum12(k + 24);            // :91
   }
   double nx, ny, nt;
+  // (sine and cosine of an angle together: one argument reduction for the two, the library's values for each)
+  double s0, c0;
+  sincos(th, &s0, &c0);
   if (mp.book || fabs(w_hat) > 0.0) {  // mc_localization.py:97-100; the book's form divides by w_hat whatever it is
     double q = v_hat / w_hat;
     double wd = w_hat * mp.dt;
-    nx = x - q * sin(th) + q * sin(th + wd);
-    ny = y + q * cos(th) - q * cos(th + wd);
+    double s1, c1;
+    sincos(th + wd, &s1, &c1);
+    nx = x - q * s0 + q * s1;
+    ny = y + q * c0 - q * c1;
     nt = th + wd + g_hat * mp.dt;
   } else {  // :101-104
-    nx = x + v_hat * cos(th) * mp.dt;
-    ny = y + v_hat * sin(th) * mp.dt;
+    nx = x + v_hat * c0 * mp.dt;
+    ny = y + v_hat * s0 * mp.dt;
     nt = th + g_hat * mp.dt;
   }
   T sx = (T)nx, sy = (T)ny, st = (T)nt;
