@@ -552,12 +552,19 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
   // spread them into scalar registers.  A vector load waits behind the in-order vector-memory counter until its
   // register is used; scalar loads share a counter with LDS, so the first LDS read after one would wait for it.)
   unsigned int n_rec = 0u;
+  // (the launch over the left-over list: the slice of cells the motion kernel noted in the particle's record -- start,
+  // length of the prefix of its tile's list that the pose can reach, flags -- comes with the pose, a particle ahead:
+  // no read of the tile's bounds behind the pose, and the prefix instead of the whole list)
+  uint4 n_slice = make_uint4(0u, 0u, 0u, 0u);
   auto fetch_next = [&]() {
     if constexpr (IVONLY) {
       n_rec = reinterpret_cast<const unsigned int*>(qrec + p_next)[lane0 & 7];
     } else {
       nx = xs[p_next]; ny = ys[p_next]; nth = ths[p_next];
       if (!STAGE && !GRID) npm = pm[p_next];
+      if constexpr (LISTED && FAST) {
+        if (qrec != nullptr) n_slice = reinterpret_cast<const uint4*>(qrec + p_next)[1];
+      }
     }
   };
   bool have = next_particle();
@@ -624,8 +631,14 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * WPB, 64 * WPB),
       first_cell = c_first;
       n_cells = c_ncells;
     } else {
+      bool noted = false;
+      if constexpr (LISTED && FAST) {
+        // (bits 1 and 2 of the flags: the record holds the slice -- see QueryRecord)
+        noted = qrec != nullptr && (n_slice.w & 6u) != 0u;
+        if (noted) { first_cell = (uint64_t)n_slice.x | ((uint64_t)n_slice.y << 32); n_cells = n_slice.z; }
+      }
       const int ex = tcx + rtx, ey = tcy + rty;
-      if (pose_ok && fabs(th) < INFINITY && ex >= 0 && ex < ETW && ey >= 0 && ey < ETH && (!IVONLY || use_iv)) {
+      if (!noted && pose_ok && fabs(th) < INFINITY && ex >= 0 && ex < ETW && ey >= 0 && ey < ETH && (!IVONLY || use_iv)) {
         const uint64_t* no = nbr_off + ((size_t)ey * ETW + ex);
         first_cell = no[0];
         n_cells = (unsigned int)(no[1] - first_cell);
@@ -1797,7 +1810,7 @@ int launch_raycast(mclhip_ctx* c, const void* x, const void* y, const void* th, 
           MCL_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks_b), block.x == 64u * kWavesPerBlock ? block : dim3(64 * kWavesPerBlock), lds_b, c->stream, P,
                            (const float*)x, (const float*)y, (const float*)th, pm, n, w_out, logw_out, ranges_out, hits_out,
-                           (const QueryRecord*)nullptr);
+                           qrec);
       }
       timing_end(c);
       c->every_last = every;

@@ -26,12 +26,21 @@ def _local_lut(lut, cell, poses, reach):
 
 
 def _free_device_bytes():
-    """hipMemGetInfo of the HIP runtime the library itself is linked against (already loaded with it)."""
+    """hipMemGetInfo of a HIP runtime this process has loaded and initialised: the one the library is linked against
+    (under /opt/rocm) first -- a process that has imported torch holds torch's own copy too, and a bare
+    dlopen("libamdhip64.so") may then come back with an instance that sees no device."""
     import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
-    free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
-    assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
-    return free.value
+    paths = {line.split()[-1] for line in open("/proc/self/maps") if "libamdhip64" in line}
+    assert paths, "no HIP runtime loaded"
+    codes = []
+    for path in sorted(paths, key=lambda q: (not q.startswith("/opt/rocm"), q)):
+        hip = ctypes.CDLL(path)
+        free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        rc = hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total))
+        if rc == 0:
+            return free.value
+        codes.append((path, rc))
+    raise AssertionError("hipMemGetInfo failed: %r" % (codes,))
 
 
 @pytest.fixture(scope="module")
